@@ -1,0 +1,381 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/*.npz by RUNNING THE REFERENCE'S OWN CODE.
+
+Runs only in the authoring container (needs /root/reference); the GPU box only sees the
+committed .npz files.  The reference modules are imported from where they lie (by file path
+for the three dependency-free files, as a package -- with an empty stand-in for the missing
+``gdown`` download helper, which the hot path never calls -- for ``annotate_model``).
+Nothing from the reference is copied into this repository: the fixtures hold only inputs,
+weights drawn here, and the outputs the reference produced for them.
+
+    python tests/golden/make_golden.py          # rewrites tests/golden/*.npz
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF_ROOT = "/root/reference"
+REF = os.path.join(REF_ROOT, "phonlp")
+OUT = os.path.dirname(os.path.abspath(__file__))
+sys.setrecursionlimit(20000)
+
+
+def load_by_path(rel, name):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+bia = load_by_path("models/common/biaffine.py", "ref_biaffine")
+crf = load_by_path("models/common/crf.py", "ref_crf")
+cle = load_by_path("models/common/chuliu_edmonds.py", "ref_cle")
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **arrs)
+    print(f"wrote {path}: {os.path.getsize(path) / 1024:.1f} KiB, {len(arrs)} arrays")
+
+
+# ---------------------------------------------------------------------------- F1 biaffine
+def gen_biaffine():
+    g = torch.Generator().manual_seed(101)
+    arrs = {}
+    cases = [(2, 5, 7, 6, 5, 1), (2, 5, 7, 6, 5, 5), (3, 9, 9, 8, 8, 33), (1, 4, 4, 3, 3, 2)]
+    for c, (B, L1, L2, D1, D2, O) in enumerate(cases):
+        m = bia.PairwiseBilinear(D1, D2, O)
+        with torch.no_grad():
+            m.weight.copy_(torch.randn(D1, D2, O, generator=g))
+            m.bias.copy_(torch.randn(O, generator=g) + 3.0)  # non-zero: proves it is ignored
+        x1 = torch.randn(B, L1, D1, generator=g)
+        x2 = torch.randn(B, L2, D2, generator=g)
+        with torch.no_grad():
+            out = m(x1, x2)
+        arrs[f"pb{c}_x1"] = x1.numpy()
+        arrs[f"pb{c}_x2"] = x2.numpy()
+        arrs[f"pb{c}_weight"] = m.weight.detach().numpy()
+        arrs[f"pb{c}_bias"] = m.bias.detach().numpy()
+        arrs[f"pb{c}_out"] = out.contiguous().numpy()
+    # full DeepBiaffineScorer (W1/W2 + relu + ones column)
+    for c, (B, L, D, H, O) in enumerate([(2, 6, 10, 7, 1), (2, 6, 10, 7, 4)]):
+        m = bia.DeepBiaffineScorer(D, D, H, O, pairwise=True, dropout=0.5).eval()
+        with torch.no_grad():
+            m.scorer.W_bilin.weight.copy_(torch.randn(H + 1, H + 1, O, generator=g) * 0.3)
+            m.scorer.W_bilin.bias.copy_(torch.randn(O, generator=g))
+        h = torch.randn(B, L, D, generator=g)
+        with torch.no_grad():
+            out = m(h, h)
+        arrs[f"db{c}_h"] = h.numpy()
+        for k, v in m.state_dict().items():
+            arrs[f"db{c}_p_{k}"] = v.numpy()
+        arrs[f"db{c}_out"] = out.contiguous().numpy()
+    arrs["n_pb"] = np.int64(len(cases))
+    arrs["n_db"] = np.int64(2)
+    save("biaffine.npz", **arrs)
+
+
+# ---------------------------------------------------------------------------- F3 viterbi
+def gen_viterbi():
+    rng = np.random.default_rng(303)
+    arrs = {}
+    n = 0
+    for (l, T, mode) in [
+        (1, 9, "rand"), (2, 9, "rand"), (17, 9, "rand"), (63, 12, "rand"), (128, 9, "rand"),
+        (31, 9, "relu_zero"), (64, 12, "relu_zero"), (40, 5, "ints"), (20, 9, "allzero"),
+        (50, 33, "rand"), (35, 64, "relu_rand"), (128, 9, "relu_rand"),
+    ]:
+        if mode == "rand":
+            s = rng.standard_normal((l, T)).astype(np.float32)
+            tr = (rng.standard_normal((T, T)) * 0.5).astype(np.float32)
+        elif mode == "relu_zero":  # ReLU'd emissions, zero-init transitions: heavy ties
+            s = np.maximum(rng.standard_normal((l, T)), 0).astype(np.float32)
+            tr = np.zeros((T, T), np.float32)
+        elif mode == "relu_rand":
+            s = np.maximum(rng.standard_normal((l, T)), 0).astype(np.float32)
+            tr = (rng.standard_normal((T, T)) * 0.1).astype(np.float32)
+        elif mode == "ints":
+            s = rng.integers(-2, 3, (l, T)).astype(np.float32)
+            tr = rng.integers(-1, 2, (T, T)).astype(np.float32)
+        else:
+            s = np.zeros((l, T), np.float32)
+            tr = np.zeros((T, T), np.float32)
+        tags, best = crf.viterbi_decode(s, tr)
+        arrs[f"v{n}_scores"] = s
+        arrs[f"v{n}_trans"] = tr
+        arrs[f"v{n}_tags"] = np.asarray(tags, dtype=np.int64)
+        arrs[f"v{n}_best"] = np.float32(best)
+        n += 1
+    arrs["n"] = np.int64(n)
+    save("viterbi.npz", **arrs)
+
+
+# ---------------------------------------------------------------------------- F4 CRF loss
+def gen_crf():
+    g = torch.Generator().manual_seed(404)
+    arrs = {}
+    n = 0
+    for (B, L, T, relu) in [(4, 11, 9, True), (3, 20, 12, False), (1, 1, 5, False), (6, 33, 9, True)]:
+        m = crf.CRFLoss(T)
+        with torch.no_grad():
+            m._transitions.copy_(torch.randn(T, T, generator=g) * 0.3)
+        x = torch.randn(B, L, T, generator=g)
+        if relu:
+            x = torch.relu(x)
+        lens = sorted([int(v) for v in torch.randint(1, L + 1, (B,), generator=g)], reverse=True)
+        lens[0] = L
+        masks = torch.ones(B, L, dtype=torch.bool)
+        for b, ln in enumerate(lens):
+            masks[b, :ln] = False
+            x[b, ln:] = 0  # pad rows are zeros in the real pipeline
+        tags = torch.randint(0, T, (B, L), generator=g)
+        with torch.no_grad():
+            m.bs, m.sl, m.nc = x.size()
+            log_norm = m.crf_log_norm(x, masks, tags)
+            loss, _ = m(x, masks, tags)
+        arrs[f"c{n}_inputs"] = x.numpy()
+        arrs[f"c{n}_masks"] = masks.numpy()
+        arrs[f"c{n}_tags"] = tags.numpy()
+        arrs[f"c{n}_trans"] = m._transitions.detach().numpy()
+        arrs[f"c{n}_log_norm"] = log_norm.numpy()
+        arrs[f"c{n}_loss"] = np.float32(loss.item())
+        n += 1
+    arrs["n"] = np.int64(n)
+    save("crf.npz", **arrs)
+
+
+# ---------------------------------------------------------------------------- F5 MST
+def log_softmax_rows(a):
+    a = a - a.max(axis=1, keepdims=True)
+    return (a - np.log(np.exp(a).sum(axis=1, keepdims=True))).astype(np.float32)
+
+
+def gen_mst():
+    rng = np.random.default_rng(505)
+    mats, outs, kinds = [], [], []
+
+    def add(m, kind):
+        m = np.ascontiguousarray(m, dtype=np.float32)
+        t = cle.chuliu_edmonds_one_root(m.copy())
+        mats.append(m)
+        outs.append(np.asarray(t, dtype=np.int64))
+        kinds.append(kind)
+
+    for l in [2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 15, 17, 20, 24, 31, 32, 33, 40, 48, 64]:
+        for rep in range(6):
+            add(log_softmax_rows(rng.standard_normal((l, l)) * 2), "randn")
+    for l in [3, 5, 8, 13, 21, 30]:
+        for rep in range(4):
+            add(rng.integers(-3, 1, (l, l)).astype(np.float32), "ints")  # massive ties
+        add(np.zeros((l, l), np.float32), "zeros")
+        add(log_softmax_rows(np.zeros((l, l))), "uniform")
+    # distance-prior-like (what a zero-init model produces): heads from |i-j| only
+    for l in [6, 11, 25, 50]:
+        i = np.arange(l)[:, None]
+        j = np.arange(l)[None, :]
+        add(log_softmax_rows(-np.log((np.abs(i - j) - 1.69) ** 2 / 2 + 1.0)), "distprior")
+    # many-root cases: column 0 strongly preferred
+    for l in [5, 9, 16, 28, 45]:
+        for rep in range(3):
+            m = rng.standard_normal((l, l)) * 1.5
+            m[:, 0] += 3.0
+            add(log_softmax_rows(m), "rooty")
+    # cycle-heavy: neighbours prefer each other
+    for l in [6, 10, 18, 36, 60]:
+        for rep in range(3):
+            m = rng.standard_normal((l, l))
+            for k in range(1, l - 1, 2):
+                m[k, k + 1] += 4
+                m[k + 1, k] += 4
+            add(log_softmax_rows(m), "pairs")
+    for l in [96, 128]:
+        for rep in range(2):
+            add(log_softmax_rows(rng.standard_normal((l, l)) * 2), "randn_big")
+    # -inf columns (as produced by masking)
+    for l in [5, 12]:
+        m = rng.standard_normal((l, l)).astype(np.float32)
+        m[:, l - 1] = -np.inf
+        add(m, "neginf_col")
+    sizes = np.asarray([m.shape[0] for m in mats], dtype=np.int64)
+    save(
+        "mst.npz",
+        sizes=sizes,
+        flat=np.concatenate([m.ravel() for m in mats]),
+        heads=np.concatenate(outs),
+        kinds=np.asarray(kinds),
+    )
+    # statistics on how many cases exercise contraction / the one-root retry
+    ncyc = nmulti = 0
+    for m in mats:
+        s = m.astype(np.float64)
+        t = cle.chuliu_edmonds(s.copy())
+        s2 = s.copy()
+        np.fill_diagonal(s2, -np.inf)
+        s2[0] = -np.inf
+        s2[0, 0] = 0
+        if len(cle.tarjan(s2.argmax(axis=1))):
+            ncyc += 1
+        if (t[1:] == 0).sum() != 1:
+            nmulti += 1
+    print(f"mst fixture: {len(mats)} cases, {ncyc} with >=1 contraction, {nmulti} needing the one-root retry")
+
+
+# ---------------------------------------------------------------------------- F2/F6 JointModel
+class ToyVocab:
+    """Minimal stand-in for the reference's vocab objects (id<->string maps only)."""
+
+    def __init__(self, units):
+        self.units = ["<PAD>", "<UNK>", "<EMPTY>", "<ROOT>"] + list(units)
+        self.index = {u: i for i, u in enumerate(self.units)}
+
+    def __len__(self):
+        return len(self.units)
+
+    def map(self, units):
+        return [self.index.get(u, 1) for u in units]
+
+    def unmap(self, ids):
+        return [self.units[int(i)] for i in ids]
+
+
+class ToyTokenizer:
+    """Deterministic stand-in tokenizer: word -> [0, 3 + hash, (optional 2nd piece), 2]."""
+
+    def __init__(self, vocab_size):
+        self.vocab_size = vocab_size
+
+    def encode(self, w):
+        h = sum((k + 1) * ord(ch) for k, ch in enumerate(w))
+        pieces = [3 + h % (self.vocab_size - 3)]
+        if len(w) > 6:
+            pieces.append(3 + (h * 7 + 1) % (self.vocab_size - 3))
+        return [0] + pieces + [2]
+
+
+def build_joint_model(seed, hidden=32, tag_emb=8, biaff=16, n_upos=6, n_rel=7, n_ner=5, zero_init=False):
+    sys.modules.setdefault("gdown", types.ModuleType("gdown"))  # download helper; never called
+    if REF_ROOT not in sys.path:
+        sys.path.insert(0, REF_ROOT)
+    from transformers import RobertaConfig
+    from phonlp.annotate_model import JointModel
+
+    torch.manual_seed(seed)
+    cfg = RobertaConfig(
+        vocab_size=200, hidden_size=hidden, num_hidden_layers=2, num_attention_heads=4,
+        intermediate_size=64, max_position_embeddings=258, pad_token_id=1, output_hidden_states=True,
+    )
+    vocab = {
+        "upos": ToyVocab([f"P{k}" for k in range(n_upos - 4)]),
+        "deprel": ToyVocab([f"rel{k}" for k in range(n_rel - 4)]),
+        "ner_tag": ToyVocab([f"N{k}" for k in range(n_ner - 4)]),
+        "word": ToyVocab([]),
+        "char": ToyVocab([]),
+    }
+    args = {"tag_emb_dim": tag_emb, "deep_biaff_hidden_dim": biaff, "dropout": 0.5, "word_dropout": 0.33,
+            "linearization": True, "distance": True}
+    model = JointModel(args, vocab, cfg, ToyTokenizer(200)).eval()
+    if not zero_init:
+        with torch.no_grad():
+            for name in ["unlabeled", "deprel", "linearization", "distance"]:
+                getattr(model, name).scorer.W_bilin.weight.normal_(0, 0.3)
+            model.upos_clf.weight.normal_(0, 0.3)
+            model.crit_ner._transitions.normal_(0, 0.3)
+    return model
+
+
+def head_state(model):
+    return {k: v.detach().numpy() for k, v in model.state_dict().items() if not k.startswith("phobert.")}
+
+
+def gen_joint(name, zero_init):
+    model = build_joint_model(seed=606, zero_init=zero_init)
+    with open(os.path.join(REF, "sample_data", "input.txt")) as f:
+        lines = [ln.strip() for ln in f if ln.strip()]
+    sents = [ln.split(" ") for ln in lines[:12]] + [["a"], ["b", "c"]]
+    arrs = {f"p_{k}": v for k, v in head_state(model).items()}
+    arrs["n_sent"] = np.int64(len(sents))
+    arrs["sent_text"] = np.asarray([" ".join(s) for s in sents])
+
+    # --- capture the hot-path inputs/outputs of dep_forward / tagger_forward on one batch
+    captured = {}
+    orig_phobert_forward = model.phobert.forward
+
+    def spy(*a, **kw):
+        out = orig_phobert_forward(*a, **kw)
+        captured.setdefault("enc_calls", []).append(out[2][-1].detach().clone())
+        return out
+
+    model.phobert.forward = spy
+    data_t = model.chunk_batches(model.process_data_tagger(batch_text=sents), len(sents))
+    data_p = model.chunk_batches(model.process_data_parser(batch_text=sents), len(sents))
+    tok, fsw, wmask, _, oidx, lens = model.get_batch(0, data_t)
+    tok1, fsw1, wmask1, _, oidx1, lens1 = model.get_batch(0, data_p)
+    with torch.no_grad():
+        preds_dep = model.dep_forward(tok1, fsw1, lens1)
+        enc_dep = captured["enc_calls"][-1]
+        preds_pos, logits = model.tagger_forward(tok, fsw, lens)
+        enc_tag = captured["enc_calls"][-1]
+    gather = lambda e, idx: torch.stack([e[i].index_select(0, idx[i]) for i in range(e.size(0))])
+    arrs["dep_enc"] = gather(enc_dep, fsw1).numpy()  # B x L x hidden: hot-path input (ROOT first)
+    arrs["dep_sentlens"] = np.asarray(lens1, dtype=np.int64)
+    arrs["dep_arc_logp"] = preds_dep[0]
+    arrs["dep_label_argmax"] = preds_dep[1]
+    arrs["tag_enc"] = gather(enc_tag, fsw).numpy()
+    arrs["tag_sentlens"] = np.asarray(lens, dtype=np.int64)
+    arrs["tag_pos_pred"] = preds_pos[0].numpy()
+    arrs["tag_ner_logits"] = logits.numpy()
+    arrs["tag_words_mask"] = wmask.numpy()
+    # decoders exactly as annotate() drives them (ref annotate_model.py:260-266, 279-286)
+    heads = [cle.chuliu_edmonds_one_root(adj[:l, :l])[1:] for adj, l in zip(preds_dep[0], lens1)]
+    rels = [[preds_dep[1][i][j + 1][h] for j, h in enumerate(hs)] for i, hs in enumerate(heads)]
+    trans = model.crit_ner._transitions.data.numpy()
+    ner = [crf.viterbi_decode(logits.numpy()[i, : lens[i]], trans)[0] for i in range(len(lens))]
+    arrs["dec_heads"] = np.concatenate(heads).astype(np.int64)
+    arrs["dec_rels"] = np.concatenate([np.asarray(r) for r in rels]).astype(np.int64)
+    arrs["dec_ner"] = np.concatenate([np.asarray(t) for t in ner]).astype(np.int64)
+    # CRF loss as predict_ner evaluates it (ref jointmodel/model.py:159)
+    gold = torch.randint(0, len(model.vocab["ner_tag"]), wmask.shape, generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        loss, _ = model.crit_ner(logits, wmask, gold)
+    arrs["crf_gold"] = gold.numpy()
+    arrs["crf_loss"] = np.float32(loss.item())
+
+    # --- F6: end-to-end annotate() over the same sentences, batch_size 5 (several ragged batches)
+    model.phobert.forward = orig_phobert_forward
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        fin, fout = os.path.join(td, "in.txt"), os.path.join(td, "out.txt")
+        with open(fin, "w") as f:
+            f.write("\n".join(" ".join(s) for s in sents) + "\n")
+        with torch.no_grad():
+            model.annotate(input_file=fin, output_file=fout, batch_size=5)
+        arrs["annotate_file"] = np.asarray(open(fout).read())
+        with torch.no_grad():
+            model.annotate(input_file=fin, output_file=fout, batch_size=5, output_type="conll")
+        arrs["annotate_file_conll"] = np.asarray(open(fout).read())
+    with torch.no_grad():
+        data, pos, nerp, dep = model.annotate(text=" ".join(sents[0]))
+    arrs["annotate_text_pos"] = np.asarray([p[0] for p in pos[0]])
+    arrs["annotate_text_ner"] = np.asarray(nerp[0])
+    arrs["annotate_text_dep_head"] = np.asarray([d[0] for d in dep[0]])
+    arrs["annotate_text_dep_rel"] = np.asarray([d[1] for d in dep[0]])
+    # encoder outputs per annotate() batch are needed to replay F6 without the encoder: store the
+    # encoder weights instead (tiny), under their own prefix.
+    for k, v in model.state_dict().items():
+        if k.startswith("phobert."):
+            arrs[f"enc_{k}"] = v.detach().numpy()
+    save(name, **arrs)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(4)
+    gen_biaffine()
+    gen_viterbi()
+    gen_crf()
+    gen_mst()
+    gen_joint("joint_small.npz", zero_init=False)
+    gen_joint("joint_zero_init.npz", zero_init=True)

@@ -1,0 +1,96 @@
+"""Pins oracle/heads_oracle.py (the CPU restatement) to outputs of the reference's own code.
+
+The fixtures were produced by tests/golden/make_golden.py, which runs the reference modules
+from /root/reference; nothing here needs the reference at run time.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import heads_oracle as O
+
+
+def _params(z, prefix="p_"):
+    return {k[len(prefix):]: torch.from_numpy(z[k]) for k in z.files if k.startswith(prefix)}
+
+
+def test_pairwise_bilinear_quirks(golden):
+    z = golden("biaffine.npz")
+    for c in range(int(z["n_pb"])):
+        x1, x2, w = (torch.from_numpy(z[f"pb{c}_{k}"]) for k in ("x1", "x2", "weight"))
+        out = O.pairwise_bilinear(x1, x2, w)
+        ref = torch.from_numpy(z[f"pb{c}_out"])
+        assert out.shape == ref.shape
+        torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-5)
+        if w.shape[2] > 1 and w.shape[0] == w.shape[1]:
+            # the documented (D1, D2, O) einsum must NOT match: the flat-reshape quirk is real
+            doc = torch.einsum("bid,deo,bje->bijo", x1, w, x2)
+            assert not torch.allclose(doc, ref, rtol=1e-3, atol=1e-3)
+
+
+def test_deep_biaffine(golden):
+    z = golden("biaffine.npz")
+    for c in range(int(z["n_db"])):
+        p = _params(z, f"db{c}_p_")
+        h = torch.from_numpy(z[f"db{c}_h"])
+        out = O.deep_biaffine(h, h, p["W1.weight"], p["W1.bias"], p["W2.weight"], p["W2.bias"],
+                              p["scorer.W_bilin.weight"])
+        torch.testing.assert_close(out, torch.from_numpy(z[f"db{c}_out"]), rtol=1e-5, atol=1e-5)
+
+
+def test_viterbi(golden):
+    z = golden("viterbi.npz")
+    for c in range(int(z["n"])):
+        tags, best = O.viterbi_decode(z[f"v{c}_scores"], z[f"v{c}_trans"])
+        assert tags == z[f"v{c}_tags"].tolist(), f"case {c}"
+        assert np.float32(best) == z[f"v{c}_best"], f"case {c}"  # single fp32 adds: bit-exact
+
+
+def test_crf_log_norm_and_loss(golden):
+    z = golden("crf.npz")
+    for c in range(int(z["n"])):
+        x, m, t, tr = (torch.from_numpy(z[f"c{c}_{k}"]) for k in ("inputs", "masks", "tags", "trans"))
+        torch.testing.assert_close(O.crf_log_norm(x, m, tr), torch.from_numpy(z[f"c{c}_log_norm"]),
+                                   rtol=1e-6, atol=1e-6)
+        assert abs(float(O.crf_nll(x, m, t, tr)) - float(z[f"c{c}_loss"])) <= 1e-5 * max(1, abs(float(z[f"c{c}_loss"])))
+
+
+def test_mst_one_root(golden):
+    z = golden("mst.npz")
+    sizes, flat, heads = z["sizes"], z["flat"], z["heads"]
+    po = ph = 0
+    for k, l in enumerate(sizes):
+        m = flat[po:po + l * l].reshape(l, l)
+        want = heads[ph:ph + l]
+        got = O.chuliu_edmonds_one_root(m)
+        assert got.tolist() == want.tolist(), f"case {k} kind {z['kinds'][k]} l={l}"
+        po += l * l
+        ph += l
+
+
+@pytest.mark.parametrize("name", ["joint_small.npz", "joint_zero_init.npz"])
+def test_joint_heads(golden, name):
+    z = golden(name)
+    p = _params(z)
+    dep = O.dep_heads(torch.from_numpy(z["dep_enc"]), z["dep_sentlens"].tolist(), p)
+    ref_arc = torch.from_numpy(z["dep_arc_logp"])
+    fin = torch.isfinite(ref_arc)
+    assert torch.equal(fin, torch.isfinite(dep["arc_logp"]))
+    torch.testing.assert_close(dep["arc_logp"][fin], ref_arc[fin], rtol=1e-4, atol=1e-5)
+    assert np.array_equal(dep["label_argmax"].numpy(), z["dep_label_argmax"])
+    tag = O.tagger_heads(torch.from_numpy(z["tag_enc"]), z["tag_sentlens"].tolist(), p)
+    assert np.array_equal(tag["pos_pred"].numpy(), z["tag_pos_pred"])
+    torch.testing.assert_close(tag["ner_logits"], torch.from_numpy(z["tag_ner_logits"]), rtol=1e-5, atol=1e-6)
+    # decoders driven the way annotate() drives them
+    lens1, lens = z["dep_sentlens"].tolist(), z["tag_sentlens"].tolist()
+    arc = z["dep_arc_logp"]
+    heads = [O.chuliu_edmonds_one_root(arc[i][:l, :l])[1:] for i, l in enumerate(lens1)]
+    assert np.concatenate(heads).tolist() == z["dec_heads"].tolist()
+    rels = [z["dep_label_argmax"][i][j + 1][h] for i, hs in enumerate(heads) for j, h in enumerate(hs)]
+    assert [int(r) for r in rels] == z["dec_rels"].tolist()
+    trans = z["p_crit_ner._transitions"]
+    ner = [O.viterbi_decode(z["tag_ner_logits"][i, :l], trans)[0] for i, l in enumerate(lens)]
+    assert [t for s in ner for t in s] == z["dec_ner"].tolist()
+    loss = O.crf_nll(torch.from_numpy(z["tag_ner_logits"]), torch.from_numpy(z["tag_words_mask"]),
+                     torch.from_numpy(z["crf_gold"]), torch.from_numpy(trans))
+    assert abs(float(loss) - float(z["crf_loss"])) <= 1e-5 * max(1.0, abs(float(z["crf_loss"])))
