@@ -1,0 +1,159 @@
+/* phonlp_heads.h -- C-ABI of the MI355X (gfx950) task-head library `libphonlp_heads.so`.
+ *
+ * Drop-in boundary for PhoNLP's task heads (everything after the PhoBERT first-subword
+ * gather).  The reference has no FFI: the seam is Python/torch, so each
+ * entry point below names the reference Python call it replaces (paths under
+ * /root/reference/phonlp).  The Python host in `phonlp_amd/` binds these with ctypes and
+ * registers them as torch custom ops; INTEGRATION.md shows the binding a reference
+ * maintainer would add.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer (hipMalloc'd / torch ROCm tensor storage) unless the
+ *    name ends in `_host`; float = IEEE fp32, row-major, 16-byte aligned where a leading
+ *    dimension is given;
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream); calls only enqueue
+ *    work, they never synchronise, allocate or free;
+ *  - scratch memory is caller-provided: ask `phonlp_*_ws_bytes()` first, pass `ws`/`ws_bytes`;
+ *  - return value: PHONLP_OK or a negative PHONLP_ERR_*; `phonlp_last_error()` gives text;
+ *  - `sentlens[b]` = number of real rows (words, incl. ROOT on the parser path) of sentence b;
+ *    rows/tokens at index >= sentlens[b] are padding.
+ */
+#ifndef PHONLP_HEADS_H
+#define PHONLP_HEADS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PHONLP_OK 0
+#define PHONLP_ERR_SHAPE (-1)       /* invalid shape / alignment / NULL argument */
+#define PHONLP_ERR_WORKSPACE (-2)   /* workspace too small */
+#define PHONLP_ERR_LAUNCH (-3)      /* HIP reported a launch error */
+#define PHONLP_ERR_UNSUPPORTED (-4) /* size beyond what the kernels support (e.g. T > 64) */
+
+/* per-sentence status written by phonlp_mst_one_root */
+#define PHONLP_MST_OK 0
+#define PHONLP_MST_NO_FINITE_TREE 1 /* ref chuliu_edmonds.py:162-168: the reference asserts here */
+
+/* Padded feature width used by the biaffine kernels for a hidden size H: H real features, one
+ * ones-column (ref biaffine.py:63-64), zero padding up to a multiple of 32. */
+int phonlp_kp(int H);
+
+int phonlp_version(void);
+const char *phonlp_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Dense layer  Y[M,N] = act(X[M,K] . W[N,K]^T + bias[N])    (fp32 MFMA, f32 accumulate)
+ * Replaces nn.Linear call sites on the path: upos_hid / upos_clf (annotate_model.py:135-136,
+ * 175-176), ner_tag_clf (:149), dep_hid (:186), DeepBiaffineScorer.W1/W2 (biaffine.py:83-85)
+ * and PairwiseBilinear stage A (biaffine.py:27-29, with W pre-transposed by
+ * phonlp_pack_bilinear).  If `sentlens` != NULL the rows are (b, i) = (m / L, m % L) and padded
+ * rows are written as exact zeros (pad_packed_sequence semantics, annotate_model.py:150,187).
+ * Requires K % 4 == 0, ldx % 4 == 0, ldw % 4 == 0, 16-byte aligned X and W.
+ */
+int phonlp_linear(const float *X, int ldx, const float *W, int ldw, const float *bias, float *Y, int ldy,
+                  int M, int N, int K, int relu, const int32_t *sentlens, int L, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Weight packing (one-time, at load).  Device-to-device kernels.
+ */
+
+/* DeepBiaffineScorer.W1/W2 (biaffine.py:73-74) -> W12[2*KP, D], b12[2*KP]: rows 0..H-1 = W1,
+ * row H = zeros with bias 1.0 (the ones column), rows H+1..KP-1 zero; then the same for W2. */
+int phonlp_pack_scorer_linear(const float *W1, const float *b1, const float *W2, const float *b2, int H, int D,
+                              float *W12, float *b12, void *stream);
+
+/* PairwiseBilinear.weight (biaffine.py:18), stored (H+1, H+1, O) -> Wbt[O*KP, KP] with
+ * Wbt[o*KP + d2][d1] = flat[d1*(H+1)*O + o*(H+1) + d2], zero elsewhere.  This bakes in the
+ * reference's flat-reshape quirk (biaffine.py:27-35).  The module's
+ * `bias` is never used by the reference (item 1) and has no counterpart here. */
+int phonlp_pack_bilinear(const float *weight, int H, int O, float *Wbt, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * POS head -- annotate_model.py:132-142 (tagger_forward) and :172-179 (dep_forward);
+ * twin jointmodel/model.py:125-137.
+ *   hid = relu(enc . Whid^T + bhid); logits = hid . Wclf^T + bclf           (per real token)
+ *   pos_pred = argmax(logits) (lowest index on ties; 0 on padded rows)
+ *   feat = [enc | softmax(logits) . emb]      (the 768+100 input of the next layer)
+ * enc: [B*L, E] (ld_enc floats per row).  feat: [B*L, E+TE] (padded rows zero).
+ * pos_pred [B*L] and upos_logits [B*L, U] are optional (NULL to skip).
+ */
+size_t phonlp_pos_head_ws_bytes(int B, int L, int E, int H, int U, int TE);
+int phonlp_pos_head(const float *enc, int ld_enc, const int32_t *sentlens, int B, int L, int E,
+                    const float *Whid, const float *bhid, const float *Wclf, const float *bclf, const float *emb,
+                    int H, int U, int TE, float *feat, int32_t *pos_pred, float *upos_logits,
+                    void *ws, size_t ws_bytes, void *stream);
+
+/* NER emissions -- annotate_model.py:149-150: logits[B,L,T] = pad(relu(feat . Wner^T + bner)). */
+int phonlp_ner_emission(const float *feat, int D, const int32_t *sentlens, int B, int L,
+                        const float *Wner, const float *bner, int T, float *logits, void *stream);
+
+/* dep_hid -- annotate_model.py:186-187: hidden[B*L, D] = pad(feat . Wdep^T + bdep). */
+int phonlp_dep_hidden(const float *feat, int D, const int32_t *sentlens, int B, int L,
+                      const float *Wdep, const float *bdep, float *hidden, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Arc scores -- annotate_model.py:189,192-214 (twin jointmodel/model.py:185-207,239):
+ *   unlabeled/linearization/distance DeepBiaffineScorers (O=1) on hidden (both sides),
+ *   arc = unl + logsigmoid(lin*sign(j-i)) + (-log((|j-i| - 1 - softplus(dist))^2/2 + 1)),
+ *   diagonal = -inf, log_softmax over ALL L head columns (padding included, no mask).
+ * n_scorers = 1 (unlabeled only), or 3 (unlabeled, linearization, distance; either optional
+ * one can be disabled with use_lin/use_dist = 0 but the pack keeps its slot).
+ * W12 [n_scorers*2*KP, D], b12 [n_scorers*2*KP], Wbt [n_scorers*KP, KP] from the pack calls.
+ * arc_logp [B,L,L].  raw_opt: NULL or [3,B,L,L] receiving the raw scorer outputs.
+ */
+size_t phonlp_biaffine_arc_ws_bytes(int B, int L, int H, int n_scorers);
+int phonlp_deep_biaffine_arc(const float *hidden, int D, int B, int L, int H, int n_scorers, int use_lin, int use_dist,
+                             const float *W12, const float *b12, const float *Wbt,
+                             float *arc_logp, float *raw_opt, void *ws, size_t ws_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Label scores -- annotate_model.py:190,215 (deprel DeepBiaffineScorer + .max(3)[1]):
+ *   label_argmax[b,i,j] = argmax_o score[b,i,j,o], lowest o on ties (int32; the Python seam
+ *   widens to int64).  scores_opt: NULL or [B,L,O,L] (the reference's memory order,
+ *   biaffine.py:35) receiving every score.
+ */
+size_t phonlp_biaffine_label_ws_bytes(int B, int L, int H, int O);
+int phonlp_deep_biaffine_label(const float *hidden, int D, int B, int L, int H, int O,
+                               const float *W12, const float *b12, const float *Wbt,
+                               int32_t *label_argmax, float *scores_opt, void *ws, size_t ws_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Viterbi -- models/common/crf.py:103-126 (viterbi_decode), per sentence on logits[b,:len].
+ * trans[prev*T + cur].  tags [B,L] (entries >= len are set to 0), best [B] or NULL.
+ * One wavefront per sentence; T <= 64.
+ */
+int phonlp_crf_viterbi(const float *logits, const float *trans, const int32_t *sentlens, int B, int L, int T,
+                       int32_t *tags, float *best, void *stream);
+
+/* CRF forward algorithm -- crf.py:79-100 (crf_log_norm) and the gold-path scores :48-77.
+ * pad_mask [B,L] bytes (non-zero = padding, the reference's `masks`) and/or sentlens, either may
+ * be NULL.  gold_tags (int32 [B,L]) optional: when given, unary[B] and binary[B] are written.
+ * log_norm [B].  T <= 64.
+ */
+int phonlp_crf_log_partition(const float *logits, const float *trans, const uint8_t *pad_mask,
+                             const int32_t *sentlens, const int32_t *gold_tags, int B, int L, int T,
+                             float *log_norm, float *unary, float *binary, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Chu-Liu-Edmonds single-root MST -- models/common/chuliu_edmonds.py:133-169, applied to
+ * arc[b, :len, :len] (rows = dependents, cols = heads, node 0 = ROOT), float64 arithmetic,
+ * the reference's tie-breaking and contraction order.  heads [B,L] int32 (heads[b,0] = 0;
+ * entries >= len set to 0); status [B] int32 (PHONLP_MST_*).  One workgroup per sentence.
+ */
+size_t phonlp_mst_ws_bytes(int B, int L);
+int phonlp_mst_one_root(const float *arc, const int32_t *sentlens, int B, int L,
+                        int32_t *heads, int32_t *status, void *ws, size_t ws_bytes, void *stream);
+
+/* Decode glue -- annotate_model.py:263-266: rel[b,i] = label_argmax[b, i, heads[b,i]] for
+ * 1 <= i < len, 0 elsewhere. */
+int phonlp_gather_labels(const int32_t *label_argmax, const int32_t *heads, const int32_t *sentlens, int B, int L,
+                         int32_t *rels, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PHONLP_HEADS_H */

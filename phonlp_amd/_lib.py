@@ -1,0 +1,63 @@
+"""ctypes binding of the C-ABI in include/phonlp_heads.h.  Fails loudly when the HIP library is missing:
+there is no CPU or PyTorch fallback anywhere in this package."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libphonlp_heads.so")
+
+_i, _z, _p = ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p
+
+# name -> (restype, argtypes); mirrors include/phonlp_heads.h declaration by declaration
+SIGNATURES = {
+    "phonlp_kp": (_i, [_i]),
+    "phonlp_version": (_i, []),
+    "phonlp_last_error": (ctypes.c_char_p, []),
+    "phonlp_linear": (_i, [_p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p, _i, _p]),
+    "phonlp_pack_scorer_linear": (_i, [_p, _p, _p, _p, _i, _i, _p, _p, _p]),
+    "phonlp_pack_bilinear": (_i, [_p, _i, _i, _p, _p]),
+    "phonlp_pos_head_ws_bytes": (_z, [_i, _i, _i, _i, _i, _i]),
+    "phonlp_pos_head": (_i, [_p, _i, _p, _i, _i, _i, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _z, _p]),
+    "phonlp_ner_emission": (_i, [_p, _i, _p, _i, _i, _p, _p, _i, _p, _p]),
+    "phonlp_dep_hidden": (_i, [_p, _i, _p, _i, _i, _p, _p, _p, _p]),
+    "phonlp_biaffine_arc_ws_bytes": (_z, [_i, _i, _i, _i]),
+    "phonlp_deep_biaffine_arc": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _z, _p]),
+    "phonlp_biaffine_label_ws_bytes": (_z, [_i, _i, _i, _i]),
+    "phonlp_deep_biaffine_label": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _z, _p]),
+    "phonlp_crf_viterbi": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _p]),
+    "phonlp_crf_log_partition": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p]),
+    "phonlp_mst_ws_bytes": (_z, [_i, _i]),
+    "phonlp_mst_one_root": (_i, [_p, _p, _i, _i, _p, _p, _p, _z, _p]),
+    "phonlp_gather_labels": (_i, [_p, _p, _p, _i, _i, _p, _p]),
+}
+
+
+class HeadsLibraryError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Loads libphonlp_heads.so once.  Raises if it has not been built (python -m phonlp_amd.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HeadsLibraryError(
+                f"{LIB_PATH} is missing: build it with `python -m phonlp_amd.build` (hipcc, gfx950). "
+                "phonlp_amd has no CPU fallback."
+            )
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the library does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().phonlp_last_error().decode("utf-8", "replace")
+        raise HeadsLibraryError(f"{what} failed with code {rc}: {msg}")

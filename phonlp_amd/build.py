@@ -1,0 +1,42 @@
+"""Builds libphonlp_heads.so (hand-written HIP, gfx950 only) in-tree with hipcc.
+
+    python -m phonlp_amd.build            # incremental: rebuilds when a source is newer than the .so
+    python -m phonlp_amd.build --force
+"""
+import glob
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_DIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIB_DIR, "libphonlp_heads.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-variable"]
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def stale():
+    if not os.path.exists(LIB):
+        return True
+    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "phonlp_heads.h")]
+    return any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps)
+
+
+def build(force=False, verbose=True):
+    if not force and not stale():
+        return LIB
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [HIPCC] + FLAGS + ["-o", LIB] + sources()
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

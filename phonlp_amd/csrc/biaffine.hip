@@ -1,0 +1,331 @@
+// Deep biaffine arc and label scoring (ref: models/common/biaffine.py, annotate_model.py:189-215).
+//
+// Data flow per call (all fp32, all resident in HBM workspace provided by the caller):
+//   hidden [M=B*L, D] --W12 GEMM + bias + ReLU--> XF [M, S*2*KP]   (X1|X2 per scorer, ones column baked
+//                                                                   in by the packed bias, zero pad)
+//   X1_s [M, KP]      --stage A GEMM (Wbt_s)--> T [M, O*KP]          (T[m][o*KP + d2])
+//   T[b], X2[b]       --stage B (per sentence)--> scores[i][j][o], consumed in the epilogue:
+//       arc:   3 scorers combined, diagonal masked, row log-softmax staged through LDS
+//       label: running arg-max over o kept in registers; the B x L x L x O tensor never exists.
+#include "mma_f32.h"
+
+namespace phonlp {
+
+int launch_linear(const float *X, long ldx, const float *W, long ldw, const float *bias, float *Y, long ldy, int M,
+                  int N, int K, int relu, const int32_t *sentlens, int L, hipStream_t stream);
+
+// ------------------------------------------------------------------------------------------ arc
+struct ArcArgs {
+    const float *T;   // [M, S*KP]
+    const float *XF;  // [M, S*2*KP]
+    float *out;       // [B, L, L] log-probabilities
+    float *raw;       // NULL or [3, B, L, L]
+    long ldT, ldx;
+    int B, L, KP, S, LP;
+    int use_lin, use_dist;
+};
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// logsigmoid / softplus exactly as torch defines them (F.logsigmoid; F.softplus beta=1, threshold=20).
+__device__ __forceinline__ float log_sigmoid(float x) { return fminf(x, 0.f) - log1pf(expf(-fabsf(x))); }
+__device__ __forceinline__ float softplus(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+
+// One block = 32 dependents (rows i) of one sentence against all L heads.  4 waves; per 128-wide
+// column group wave w owns columns [32w, 32w+32).
+__global__ __launch_bounds__(256) void arc_kernel(ArcArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *As = smem;
+    float *Bs = smem + 32 * PITCH;
+    float *rowbuf = smem + 160 * PITCH;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, i0 = blockIdx.x * 32;
+    const int L = a.L, KP = a.KP, LP = a.LP;
+    const int iv = L - i0;
+    const int nk = KP / BK;
+    const int total = a.S * nk;
+    const float *Tb = a.T + ((long)b * L + i0) * a.ldT;
+    const long plane = (long)a.B * L * L;
+
+    for (int j0 = 0; j0 < L; j0 += 128) {
+        const int jv = L - j0;
+        const float *Xb = a.XF + ((long)b * L + j0) * a.ldx;
+        f32x16 acc0[1][1], acc1[1][1], acc2[1][1];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[0][0][r] = acc1[0][0][r] = acc2[0][0][r] = 0.f;
+
+        Slab<32, 256> ra;
+        Slab<128, 256> rb;
+        slab_load(ra, Tb, a.ldT, iv, 0, KP, tid);
+        slab_load(rb, Xb + KP, a.ldx, jv, 0, KP, tid);
+        __syncthreads();  // previous column group / softmax phase done with the staging buffers
+        slab_store(ra, As, tid);
+        slab_store(rb, Bs, tid);
+        __syncthreads();
+        for (int it = 0; it < total; ++it) {
+            const int s = it / nk;
+            if (it + 1 < total) {
+                const int s2 = (it + 1) / nk, k2 = ((it + 1) % nk) * BK;
+                slab_load(ra, Tb + s2 * KP, a.ldT, iv, k2, KP, tid);
+                slab_load(rb, Xb + (2 * s2 + 1) * KP, a.ldx, jv, k2, KP, tid);
+            }
+            const float *Bw = Bs + wave * 32 * PITCH;
+            if (s == 0) mma_slab<1, 1>(As, Bw, lane, acc0);
+            else if (s == 1) mma_slab<1, 1>(As, Bw, lane, acc1);
+            else mma_slab<1, 1>(As, Bw, lane, acc2);
+            __syncthreads();
+            if (it + 1 < total) {
+                slab_store(ra, As, tid);
+                slab_store(rb, Bs, tid);
+                __syncthreads();
+            }
+        }
+        // epilogue: combine the scorers (ref annotate_model.py:192-211) into the LDS row buffer
+        const int col = j0 + wave * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = acc_row(r, lane);
+            const int i = i0 + row;
+            if (row < iv && col < L) {
+                const float u = acc0[0][0][r];
+                float v = u;
+                const int off = col - i;
+                if (a.S > 1) {
+                    const float lin = acc1[0][0][r], dst = acc2[0][0][r];
+                    if (a.raw) {
+                        const long e = ((long)b * L + i) * L + col;
+                        a.raw[e] = u;
+                        a.raw[plane + e] = lin;
+                        a.raw[2 * plane + e] = dst;
+                    }
+                    if (a.use_lin) {
+                        const float sg = off > 0 ? 1.f : (off < 0 ? -1.f : 0.f);
+                        v += log_sigmoid(lin * sg);
+                    }
+                    if (a.use_dist) {
+                        const float pred = 1.f + softplus(dst);
+                        const float d = fabsf((float)off) - pred;
+                        v += -logf(d * d / 2.f + 1.f);
+                    }
+                } else if (a.raw) {
+                    a.raw[((long)b * L + i) * L + col] = u;
+                }
+                if (off == 0) v = -INFINITY;
+                rowbuf[row * LP + col] = v;
+            }
+        }
+    }
+    __syncthreads();
+    // row-wise log-softmax over all L head columns (padding columns included, ref :214)
+    for (int row = wave; row < iv && row < 32; row += 4) {
+        const float *x = rowbuf + row * LP;
+        float m = -INFINITY;
+        for (int j = lane; j < L; j += 64) m = fmaxf(m, x[j]);
+        m = wave_max(m);
+        float s = 0.f;
+        for (int j = lane; j < L; j += 64) s += expf(x[j] - m);
+        s = wave_sum(s);
+        const float ls = logf(s);
+        float *o = a.out + ((long)b * L + i0 + row) * L;
+        for (int j = lane; j < L; j += 64) o[j] = (x[j] - m) - ls;
+    }
+}
+
+// ---------------------------------------------------------------------------------------- label
+struct LabelArgs {
+    const float *T;   // [M, O*KP]
+    const float *X2;  // [M, ldx] (already offset to the X2 half)
+    int32_t *out;     // [B, L, L]
+    float *scores;    // NULL or [B, L, O, L]
+    long ldT, ldx;
+    int B, L, O, KP;
+    int tiles;  // ceil(L / 128)
+};
+
+// One block = a 128 x 128 (dependent x head) tile of one sentence; 8 waves as 2 x 4, each wave a
+// 64 x 32 sub-tile.  The K loop runs over (o, k): after the last slab of relation o the
+// accumulators are folded into a running (max, arg-max) pair and cleared.  Strict '>' keeps the
+// lowest o on ties (CPU torch.max / np.argmax semantics).
+__global__ __launch_bounds__(512) void label_kernel(LabelArgs a) {
+    constexpr int THREADS = 512;
+    __shared__ __attribute__((aligned(16))) float lds[256 * PITCH];
+    float *As = lds, *Bs = lds + 128 * PITCH;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int L = a.L, KP = a.KP, O = a.O;
+    const int per_sent = a.tiles * a.tiles;
+    const int b = blockIdx.x / per_sent;
+    const int rem = blockIdx.x - b * per_sent;
+    const int i0 = (rem / a.tiles) * 128, j0 = (rem % a.tiles) * 128;
+    const int iv = L - i0, jv = L - j0;
+    const float *Tb = a.T + ((long)b * L + i0) * a.ldT;
+    const float *Xb = a.X2 + ((long)b * L + j0) * a.ldx;
+    const int nk = KP / BK;
+    const int total = O * nk;
+
+    f32x16 acc[2][1];
+    f32x16 best[2];
+    int arg[2][16];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            acc[i][0][r] = 0.f;
+            best[i][r] = -INFINITY;
+            arg[i][r] = 0;
+        }
+
+    Slab<128, THREADS> ra, rb;
+    slab_load(ra, Tb, a.ldT, iv, 0, KP, tid);
+    slab_load(rb, Xb, a.ldx, jv, 0, KP, tid);
+    slab_store(ra, As, tid);
+    slab_store(rb, Bs, tid);
+    __syncthreads();
+    int o = 0, kk = 0;
+    for (int it = 0; it < total; ++it) {
+        int o2 = o, k2 = kk + 1;
+        if (k2 == nk) { k2 = 0; ++o2; }
+        if (it + 1 < total) {
+            slab_load(ra, Tb + (long)o2 * KP, a.ldT, iv, k2 * BK, KP, tid);
+            slab_load(rb, Xb, a.ldx, jv, k2 * BK, KP, tid);
+        }
+        mma_slab<2, 1>(As + wm * 64 * PITCH, Bs + wn * 32 * PITCH, lane, acc);
+        if (kk == nk - 1) {
+            const int col = j0 + wn * 32 + (lane & 31);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = acc[i][0][r];
+                    if (v > best[i][r]) { best[i][r] = v; arg[i][r] = o; }
+                    if (a.scores) {
+                        const int row = i0 + wm * 64 + i * 32 + acc_row(r, lane);
+                        if (row < L && col < L) a.scores[(((long)b * L + row) * O + o) * L + col] = v;
+                    }
+                    acc[i][0][r] = 0.f;
+                }
+        }
+        __syncthreads();
+        if (it + 1 < total) {
+            slab_store(ra, As, tid);
+            slab_store(rb, Bs, tid);
+            __syncthreads();
+        }
+        o = o2;
+        kk = k2;
+    }
+    const int col = j0 + wn * 32 + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = i0 + wm * 64 + i * 32 + acc_row(r, lane);
+            if (row < L && col < L) a.out[((long)b * L + row) * L + col] = arg[i][r];
+        }
+}
+
+// rel[b,i] = label_argmax[b, i, heads[b,i]]  (ref annotate_model.py:263-266)
+__global__ void gather_labels_kernel(const int32_t *lab, const int32_t *heads, const int32_t *sentlens, int B, int L,
+                                     int32_t *rels) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * L) return;
+    const int b = idx / L, i = idx % L;
+    int v = 0;
+    if (i >= 1 && i < sentlens[b]) {
+        const int h = heads[idx];
+        if (h >= 0 && h < L) v = lab[((long)b * L + i) * L + h];
+    }
+    rels[idx] = v;
+}
+
+}  // namespace phonlp
+
+using namespace phonlp;
+
+extern "C" int phonlp_kp(int H) { return kp_of(H); }
+
+extern "C" size_t phonlp_biaffine_arc_ws_bytes(int B, int L, int H, int n_scorers) {
+    const size_t M = (size_t)B * L, KP = kp_of(H);
+    return align_up(M * n_scorers * 2 * KP * sizeof(float), 256) + align_up(M * n_scorers * KP * sizeof(float), 256);
+}
+
+extern "C" int phonlp_deep_biaffine_arc(const float *hidden, int D, int B, int L, int H, int n_scorers, int use_lin,
+                                        int use_dist, const float *W12, const float *b12, const float *Wbt,
+                                        float *arc_logp, float *raw_opt, void *ws, size_t ws_bytes, void *stream) {
+    if (!hidden || !W12 || !b12 || !Wbt || !arc_logp || B <= 0 || L <= 0 || H <= 0 || D <= 0)
+        return fail(PHONLP_ERR_SHAPE, "deep_biaffine_arc: bad argument");
+    if (n_scorers != 1 && n_scorers != 3) return fail(PHONLP_ERR_SHAPE, "deep_biaffine_arc: n_scorers must be 1 or 3");
+    if (n_scorers == 1 && (use_lin || use_dist))
+        return fail(PHONLP_ERR_SHAPE, "deep_biaffine_arc: use_lin/use_dist need n_scorers == 3");
+    if (L > 1024) return fail(PHONLP_ERR_UNSUPPORTED, "deep_biaffine_arc: L > 1024 does not fit the LDS row buffer");
+    if (ws_bytes < phonlp_biaffine_arc_ws_bytes(B, L, H, n_scorers) || !ws)
+        return fail(PHONLP_ERR_WORKSPACE, "deep_biaffine_arc: workspace too small");
+    hipStream_t st = as_stream(stream);
+    const int M = B * L, KP = kp_of(H), S = n_scorers;
+    float *XF = (float *)ws;
+    float *T = (float *)((char *)ws + align_up((size_t)M * S * 2 * KP * sizeof(float), 256));
+    int rc = launch_linear(hidden, D, W12, D, b12, XF, (long)S * 2 * KP, M, S * 2 * KP, D, 1, nullptr, 0, st);
+    if (rc) return rc;
+    for (int s = 0; s < S; ++s) {
+        rc = launch_linear(XF + 2 * s * KP, (long)S * 2 * KP, Wbt + (long)s * KP * KP, KP, nullptr, T + s * KP,
+                           (long)S * KP, M, KP, KP, 0, nullptr, 0, st);
+        if (rc) return rc;
+    }
+    ArcArgs a{T, XF, arc_logp, raw_opt, (long)S * KP, (long)S * 2 * KP, B, L, KP, S, 0, use_lin, use_dist};
+    a.LP = (L + 31) / 32 * 32 + 1;
+    const size_t lds = (size_t)(160 * PITCH + 32 * a.LP) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)arc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+            hipSuccess)
+            return fail(PHONLP_ERR_LAUNCH, "deep_biaffine_arc: cannot raise the dynamic LDS limit");
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(arc_kernel, dim3(ceil_div(L, 32), B), dim3(256), lds, st, a);
+    return check_launch("arc_kernel");
+}
+
+extern "C" size_t phonlp_biaffine_label_ws_bytes(int B, int L, int H, int O) {
+    const size_t M = (size_t)B * L, KP = kp_of(H);
+    return align_up(M * 2 * KP * sizeof(float), 256) + align_up(M * (size_t)O * KP * sizeof(float), 256);
+}
+
+extern "C" int phonlp_deep_biaffine_label(const float *hidden, int D, int B, int L, int H, int O, const float *W12,
+                                          const float *b12, const float *Wbt, int32_t *label_argmax,
+                                          float *scores_opt, void *ws, size_t ws_bytes, void *stream) {
+    if (!hidden || !W12 || !b12 || !Wbt || !label_argmax || B <= 0 || L <= 0 || H <= 0 || D <= 0 || O <= 0)
+        return fail(PHONLP_ERR_SHAPE, "deep_biaffine_label: bad argument");
+    if (ws_bytes < phonlp_biaffine_label_ws_bytes(B, L, H, O) || !ws)
+        return fail(PHONLP_ERR_WORKSPACE, "deep_biaffine_label: workspace too small");
+    hipStream_t st = as_stream(stream);
+    const int M = B * L, KP = kp_of(H);
+    float *XF = (float *)ws;
+    float *T = (float *)((char *)ws + align_up((size_t)M * 2 * KP * sizeof(float), 256));
+    int rc = launch_linear(hidden, D, W12, D, b12, XF, 2L * KP, M, 2 * KP, D, 1, nullptr, 0, st);
+    if (rc) return rc;
+    rc = launch_linear(XF, 2L * KP, Wbt, KP, nullptr, T, (long)O * KP, M, O * KP, KP, 0, nullptr, 0, st);
+    if (rc) return rc;
+    LabelArgs a{T, XF + KP, label_argmax, scores_opt, (long)O * KP, 2L * KP, B, L, O, KP, ceil_div(L, 128)};
+    hipLaunchKernelGGL(label_kernel, dim3(B * a.tiles * a.tiles), dim3(512), 0, st, a);
+    return check_launch("label_kernel");
+}
+
+extern "C" int phonlp_gather_labels(const int32_t *label_argmax, const int32_t *heads, const int32_t *sentlens, int B,
+                                    int L, int32_t *rels, void *stream) {
+    if (!label_argmax || !heads || !sentlens || !rels || B <= 0 || L <= 0)
+        return fail(PHONLP_ERR_SHAPE, "gather_labels: bad argument");
+    hipLaunchKernelGGL(gather_labels_kernel, dim3(ceil_div(B * L, 256)), dim3(256), 0, as_stream(stream), label_argmax,
+                       heads, sentlens, B, L, rels);
+    return check_launch("gather_labels_kernel");
+}

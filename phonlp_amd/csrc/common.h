@@ -1,0 +1,26 @@
+// Shared host/device helpers for libphonlp_heads.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/phonlp_heads.h"
+
+namespace phonlp {
+
+// Records a printf-style message for phonlp_last_error() (thread-local) and returns `code`.
+int fail(int code, const char *fmt, ...);
+
+// Checks the launch that was just enqueued.
+int check_launch(const char *what);
+
+constexpr int kWave = 64;
+
+__host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+__host__ __device__ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+// KP: hidden features + ones column, zero-padded to the MFMA slab depth (32).
+__host__ __device__ inline int kp_of(int H) { return (H + 1 + 31) / 32 * 32; }
+
+}  // namespace phonlp

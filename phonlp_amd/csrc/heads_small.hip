@@ -1,0 +1,116 @@
+// POS head tail (softmax / arg-max / soft POS embedding), NER emissions, dep_hid, and the error plumbing.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "common.h"
+
+namespace phonlp {
+
+static thread_local char g_err[256] = "";
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int check_launch(const char *what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(PHONLP_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return PHONLP_OK;
+}
+
+int launch_linear(const float *X, long ldx, const float *W, long ldw, const float *bias, float *Y, long ldy, int M,
+                  int N, int K, int relu, const int32_t *sentlens, int L, hipStream_t stream);
+
+// One wavefront per token.  logits [M, U] (U <= 64) -> pos_pred, feat = [enc | softmax(logits) . emb].
+// ref annotate_model.py:138-146 / :177-183.
+__global__ __launch_bounds__(256) void pos_tail_kernel(const float *enc, long ld_enc, const float *logits,
+                                                       const float *emb, const int32_t *sentlens, int M, int L, int E,
+                                                       int U, int TE, float *feat, int32_t *pos_pred) {
+    const int lane = threadIdx.x & 63;
+    const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tok >= M) return;
+    const int b = tok / L, i = tok % L;
+    float *frow = feat + (long)tok * (E + TE);
+    if (i >= sentlens[b]) {  // padding: pad_packed_sequence zeros, arg-max of a zero row = 0
+        for (int c = lane; c < E + TE; c += 64) frow[c] = 0.f;
+        if (pos_pred && lane == 0) pos_pred[tok] = 0;
+        return;
+    }
+    const float x = lane < U ? logits[(long)tok * U + lane] : -INFINITY;
+    float best = x;
+    int bi = lane;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float v2 = __shfl_xor(best, o);
+        const int i2 = __shfl_xor(bi, o);
+        if (v2 > best || (v2 == best && i2 < bi)) { best = v2; bi = i2; }
+    }
+    if (pos_pred && lane == 0) pos_pred[tok] = bi;
+    float p = lane < U ? expf(x - best) : 0.f;
+    float s = p;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    p = p / s;
+    for (int d = lane; d < TE; d += 64) {
+        float acc = 0.f;
+        for (int u = 0; u < U; ++u) acc += __shfl(p, u) * emb[u * TE + d];
+        frow[E + d] = acc;
+    }
+    const float *erow = enc + (long)tok * ld_enc;
+    for (int c = lane * 4; c < E; c += 256) *reinterpret_cast<float4 *>(frow + c) = *reinterpret_cast<const float4 *>(erow + c);
+}
+
+}  // namespace phonlp
+
+using namespace phonlp;
+
+extern "C" int phonlp_version(void) { return 100; }
+extern "C" const char *phonlp_last_error(void) { return g_err; }
+
+extern "C" size_t phonlp_pos_head_ws_bytes(int B, int L, int E, int H, int U, int TE) {
+    (void)E; (void)TE;
+    const size_t M = (size_t)B * L;
+    return align_up(M * H * sizeof(float), 256) + align_up(M * U * sizeof(float), 256);
+}
+
+extern "C" int phonlp_pos_head(const float *enc, int ld_enc, const int32_t *sentlens, int B, int L, int E,
+                               const float *Whid, const float *bhid, const float *Wclf, const float *bclf,
+                               const float *emb, int H, int U, int TE, float *feat, int32_t *pos_pred,
+                               float *upos_logits, void *ws, size_t ws_bytes, void *stream) {
+    if (!enc || !sentlens || !Whid || !bhid || !Wclf || !bclf || !emb || !feat || B <= 0 || L <= 0)
+        return fail(PHONLP_ERR_SHAPE, "pos_head: bad argument");
+    if (U > 64 || U <= 0) return fail(PHONLP_ERR_UNSUPPORTED, "pos_head: needs 1 <= U <= 64 (one lane per tag)");
+    if ((E & 3) || (H & 3) || ((E + TE) & 3) || (ld_enc & 3) || ((uintptr_t)feat & 15))
+        return fail(PHONLP_ERR_SHAPE, "pos_head: E, H, E+TE, ld_enc must be multiples of 4 and feat 16-byte aligned");
+    if (!ws || ws_bytes < phonlp_pos_head_ws_bytes(B, L, E, H, U, TE))
+        return fail(PHONLP_ERR_WORKSPACE, "pos_head: workspace too small");
+    hipStream_t st = as_stream(stream);
+    const int M = B * L;
+    float *hid = (float *)ws;
+    float *logits = upos_logits ? upos_logits : (float *)((char *)ws + align_up((size_t)M * H * sizeof(float), 256));
+    int rc = launch_linear(enc, ld_enc, Whid, E, bhid, hid, H, M, H, E, 1, sentlens, L, st);
+    if (rc) return rc;
+    rc = launch_linear(hid, H, Wclf, H, bclf, logits, U, M, U, H, 0, sentlens, L, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(pos_tail_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, st, enc, (long)ld_enc, logits, emb, sentlens,
+                       M, L, E, U, TE, feat, pos_pred);
+    return check_launch("pos_tail_kernel");
+}
+
+extern "C" int phonlp_ner_emission(const float *feat, int D, const int32_t *sentlens, int B, int L, const float *Wner,
+                                   const float *bner, int T, float *logits, void *stream) {
+    if (!feat || !sentlens || !Wner || !logits || B <= 0 || L <= 0 || T <= 0)
+        return fail(PHONLP_ERR_SHAPE, "ner_emission: bad argument");
+    return launch_linear(feat, D, Wner, D, bner, logits, T, B * L, T, D, 1, sentlens, L, as_stream(stream));
+}
+
+extern "C" int phonlp_dep_hidden(const float *feat, int D, const int32_t *sentlens, int B, int L, const float *Wdep,
+                                 const float *bdep, float *hidden, void *stream) {
+    if (!feat || !sentlens || !Wdep || !hidden || B <= 0 || L <= 0)
+        return fail(PHONLP_ERR_SHAPE, "dep_hidden: bad argument");
+    return launch_linear(feat, D, Wdep, D, bdep, hidden, D, B * L, D, D, 0, sentlens, L, as_stream(stream));
+}

@@ -1,0 +1,397 @@
+// Chu-Liu-Edmonds single-root MST decoding (ref models/common/chuliu_edmonds.py), one workgroup
+// per sentence, float64 arithmetic, bit-identical trees to the reference.
+//
+// The reference is recursive: arg-max every row, list the cycles with Tarjan, contract the LAST
+// listed cycle into a fresh (n-c+1)^2 matrix, recurse, expand.  This kernel runs the same
+// sequence of contractions iteratively on ONE l x l float64 matrix held in LDS:
+//   * a contracted level is described by `node[]`: logical index (the reference's row/column
+//     order at that level) -> physical slot of the matrix.  Contracting a cycle keeps the
+//     non-cycle nodes in order and appends the metanode last (ref :93-99); its row/column reuse
+//     the slot of the cycle's first member, so nothing is ever compacted or copied;
+//   * "the last cycle Tarjan lists" is the cycle whose smallest member is largest: a cycle of a
+//     head-pointer graph can only be entered from its own members, so ref tarjan (:46-48) closes
+//     cycles in ascending order of their smallest node.  Cycle membership and each cycle's
+//     minimum come from log2(n) rounds of pointer doubling -- no serial DFS;
+//   * rows whose best head was outside the contracted cycle keep it (their other entries are
+//     unchanged, the new metanode column holds a value <= the old maximum and is ordered last,
+//     so np.argmax's first-maximum rule picks the same column); only rows that pointed into
+//     the cycle, and the metanode's row, are re-scanned;
+//   * per level the O(n) index arrays needed for the expansion (ref :105-128) are pushed on a
+//     per-sentence stack in the caller's workspace.
+// Every float64 operation matches the reference's: (s - edge) + total (:84), numpy's pairwise
+// summation order for cycle_scores.sum() (:75) and tree_probs.sum() (:158), strict '>' for
+// first-maximum ties.
+#include <limits.h>
+
+#include "common.h"
+
+namespace phonlp {
+
+struct MstArgs {
+    const float *arc;
+    const int32_t *sentlens;
+    int32_t *heads;
+    int32_t *status;
+    uint16_t *stack;
+    double *gmat;
+    long stack_stride;  // u16 per sentence
+    long gmat_stride;   // doubles per sentence
+    int B, L, pitch, lvl_stride;
+};
+
+#define NEG_INF_D (-__builtin_inf())
+
+// numpy's float64 pairwise add-reduction order (verified against numpy 2.2, n = 1..1000).
+__device__ inline double np_sum_block(const double *a, int n) {
+    if (n < 8) {
+        double r = 0.0;
+        for (int i = 0; i < n; ++i) r += a[i];
+        return r;
+    }
+    double r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
+    int i = 8;
+    for (; i < n - (n % 8); i += 8) {
+        r0 += a[i]; r1 += a[i + 1]; r2 += a[i + 2]; r3 += a[i + 3];
+        r4 += a[i + 4]; r5 += a[i + 5]; r6 += a[i + 6]; r7 += a[i + 7];
+    }
+    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < n; ++i) res += a[i];
+    return res;
+}
+template <int DEPTH>
+__device__ inline double np_sum(const double *a, int n) {
+    if (n <= 128) return np_sum_block(a, n);
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_sum<DEPTH - 1>(a, n2) + np_sum<DEPTH - 1>(a + n2, n - n2);
+}
+template <>
+__device__ inline double np_sum<0>(const double *a, int n) { return np_sum_block(a, n); }
+
+// scalars kept in LDS
+enum { SC_M = 0, SC_NEXT, SC_NROOT, SC_FINITE, SC_C, SC_TAKE, SC_COUNT = 16 };
+
+template <bool IN_LDS>
+__global__ __launch_bounds__(1024) void mst_kernel(MstArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int b = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, nwaves = NT >> 6;
+    const int L = a.L, pitch = a.pitch;
+    int l = a.sentlens[b];
+    if (l > L) l = L;
+    int32_t *hout = a.heads + (long)b * L;
+    for (int t = tid; t < L; t += NT) hout[t] = 0;
+    if (l <= 1) {  // l == 1: ROOT only -- the reference hits its broken assert (no candidate root)
+        if (tid == 0) a.status[b] = l == 1 ? PHONLP_MST_NO_FINITE_TREE : PHONLP_MST_OK;
+        return;
+    }
+    // ---- carve LDS
+    size_t off = 0;
+    double *S;
+    if (IN_LDS) {
+        S = reinterpret_cast<double *>(smem_raw);
+        off = (size_t)L * pitch * sizeof(double);
+    } else {
+        S = a.gmat + (long)b * a.gmat_stride;
+    }
+    double *ev = reinterpret_cast<double *>(smem_raw + off); off += (size_t)L * 8;
+    double *lv = reinterpret_cast<double *>(smem_raw + off); off += (size_t)L * 8;
+    double *edge = reinterpret_cast<double *>(smem_raw + off); off += (size_t)L * 8;
+    double *dsc = reinterpret_cast<double *>(smem_raw + off); off += 4 * 8;
+    int *ibase = reinterpret_cast<int *>(smem_raw + off);
+    int *node = ibase, *hdA = node + L, *hdB = hdA + L, *P0 = hdB + L, *P1 = P0 + L, *mn0 = P1 + L, *mn1 = mn0 + L;
+    int *flag = mn1 + L, *incyc = flag + L, *rankr = incyc + L, *cyc = rankr + L, *rest = cyc + L;
+    int *epick = rest + L, *lpick = epick + L, *need = lpick + L, *tree0 = need + L, *besttree = tree0 + L;
+    int *sc = besttree + L;
+    int *wtot = sc + SC_COUNT;  // 16 entries
+
+    const float *arc = a.arc + (long)b * L * L;
+    uint16_t *stack = a.stack + (long)b * a.stack_stride;
+#define SM(r, c) S[(long)(r) * pitch + (c)]
+
+    int root = -1;  // -1: unconstrained first run (ref :137); >= 1: set_root(root) (ref :143-149)
+    double best_score = NEG_INF_D;
+    int have_best = 0;
+    int err = 0;
+
+    for (;;) {
+        // -------------------------------------------------------------- load + edit the matrix
+        for (int idx = tid; idx < l * l; idx += NT) {
+            const int i = idx / l, j = idx - i * l;
+            double v = (double)arc[(long)i * L + j];
+            if (root >= 1) {
+                if (j == 0 && i >= 1) v = NEG_INF_D;
+                if (i == root) v = j == 0 ? 0.0 : NEG_INF_D;
+            }
+            if (i == j) v = NEG_INF_D;                      // ref :55
+            if (i == 0) v = j == 0 ? 0.0 : NEG_INF_D;       // ref :56-57
+            SM(i, j) = v;
+        }
+        if (tid < l) { node[tid] = tid; need[tid] = 1; }
+        int n = l, levels = 0;
+        __syncthreads();
+
+        // -------------------------------------------------------------- contraction loop
+        for (;;) {
+            // (1) first-maximum arg-max of every row that needs it, in logical column order
+            for (int row = wave; row < n; row += nwaves) {
+                if (!need[row]) continue;
+                const int rs = node[row];
+                double bv = NEG_INF_D;
+                int bi = INT_MAX;
+                if (lane < n) { bv = SM(rs, node[lane]); bi = lane; }
+                for (int c = lane + 64; c < n; c += 64) {
+                    const double v = SM(rs, node[c]);
+                    if (v > bv) { bv = v; bi = c; }
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const double v2 = __shfl_xor(bv, o);
+                    const int i2 = __shfl_xor(bi, o);
+                    if (v2 > bv || (v2 == bv && i2 < bi)) { bv = v2; bi = i2; }
+                }
+                if (lane == 0) hdA[row] = bi;
+            }
+            __syncthreads();
+            // (2) cycles by pointer doubling: after R rounds (2^R >= n) P[v] lies on v's cycle and
+            //     mn[v] is the minimum over >= n consecutive nodes, i.e. the whole cycle for cycle nodes
+            if (tid < n) { P0[tid] = hdA[tid]; mn0[tid] = tid; flag[tid] = 0; }
+            if (tid == 0) sc[SC_M] = 0;
+            __syncthreads();
+            int *Pc = P0, *Pn = P1, *mc = mn0, *mx = mn1;
+            for (int span = 1; span < n; span <<= 1) {
+                if (tid < n) {
+                    const int p = Pc[tid];
+                    Pn[tid] = Pc[p];
+                    const int m1 = mc[tid], m2 = mc[p];
+                    mx[tid] = m1 < m2 ? m1 : m2;
+                }
+                __syncthreads();
+                int *t1 = Pc; Pc = Pn; Pn = t1;
+                int *t2 = mc; mc = mx; mx = t2;
+            }
+            if (tid < n) flag[Pc[tid]] = 1;
+            __syncthreads();
+            if (tid < n && flag[tid]) atomicMax(&sc[SC_M], mc[tid]);
+            __syncthreads();
+            const int M = sc[SC_M];
+            if (M == 0) break;  // only ROOT's self loop is left: hdA is a tree
+            if (levels >= l) { err = 1; break; }
+            // (3) the chosen cycle, member / non-member lists in ascending logical order
+            int f = 0;
+            if (tid < n) { f = (flag[tid] && mc[tid] == M) ? 1 : 0; incyc[tid] = f; }
+            const unsigned long long bal = __ballot(f);
+            if (lane == 0) wtot[wave] = __popcll(bal);
+            __syncthreads();
+            int rc = __popcll(bal & ((1ull << lane) - 1ull));
+            int c = 0;
+            for (int w = 0; w < nwaves; ++w) {
+                const int wt = wtot[w];
+                if (w < wave) rc += wt;
+                c += wt;
+            }
+            const int k = n - c;
+            if (tid < n) {
+                if (f) cyc[rc] = tid;
+                else rest[tid - rc] = tid;
+                rankr[tid] = tid - rc;
+            }
+            __syncthreads();
+            // (4) cycle edge scores and their numpy-ordered sum (ref :73-75)
+            if (tid < c) {
+                const int v = cyc[tid];
+                edge[tid] = SM(node[v], node[hdA[v]]);
+            }
+            __syncthreads();
+            if (tid == 0) dsc[0] = np_sum<4>(edge, c);
+            __syncthreads();
+            const double total = dsc[0];
+            // (5) best way into the cycle from every outside node (ref :84,:88,:97) and best head
+            //     inside the cycle for every outside node (ref :86,:90,:99)
+            int my_slot = 0, my_newhead = 0, my_need = 0;
+            double my_ev = 0.0, my_lv = 0.0;
+            const int ms = node[cyc[0]];  // slot the metanode will live in
+            if (tid < k) {
+                const int x = tid;
+                const int old = rest[x];
+                my_slot = node[old];
+                double be = (SM(node[cyc[0]], my_slot) - edge[0]) + total;
+                int ae = 0;
+                double bl = SM(my_slot, node[cyc[0]]);
+                int al = 0;
+                for (int q = 1; q < c; ++q) {
+                    const int cs = node[cyc[q]];
+                    const double ve = (SM(cs, my_slot) - edge[q]) + total;
+                    if (ve > be) { be = ve; ae = q; }
+                    const double vl = SM(my_slot, cs);
+                    if (vl > bl) { bl = vl; al = q; }
+                }
+                my_ev = be; my_lv = bl;
+                epick[x] = ae; lpick[x] = al;
+                const int h = hdA[old];
+                if (incyc[h]) { my_need = 1; my_newhead = 0; }
+                else my_newhead = rankr[h];
+            }
+            // (6) push this level's expansion record
+            {
+                uint16_t *rec = stack + (long)levels * a.lvl_stride;
+                if (tid == 0) { rec[0] = (uint16_t)n; rec[1] = (uint16_t)c; }
+                if (tid < n) rec[2 + tid] = (uint16_t)hdA[tid];
+                if (tid < c) rec[2 + n + tid] = (uint16_t)cyc[tid];
+                if (tid < k) {
+                    rec[2 + n + c + tid] = (uint16_t)rest[tid];
+                    rec[2 + n + c + k + tid] = (uint16_t)epick[tid];
+                    rec[2 + n + c + 2 * k + tid] = (uint16_t)lpick[tid];
+                }
+            }
+            __syncthreads();
+            // (7) contract in place: metanode row/column into slot `ms`, new logical order
+            if (tid < k) {
+                SM(ms, my_slot) = my_ev;
+                SM(my_slot, ms) = my_lv;
+                node[tid] = my_slot;
+                hdA[tid] = my_newhead;
+                need[tid] = my_need;
+            }
+            if (tid == 0) {
+                SM(ms, ms) = NEG_INF_D;
+                node[k] = ms;
+                need[k] = 1;
+            }
+            n = k + 1;
+            ++levels;
+            __syncthreads();
+        }
+        if (err) break;
+        // -------------------------------------------------------------- expansion (ref :105-128)
+        int *cur = hdA, *oth = hdB;
+        for (int lev = levels - 1; lev >= 0; --lev) {
+            const uint16_t *rec = stack + (long)lev * a.lvl_stride;
+            const int np_ = rec[0], c = rec[1], k = np_ - c;
+            const uint16_t *r_hd = rec + 2, *r_cyc = r_hd + np_, *r_rest = r_cyc + c, *r_ep = r_rest + k, *r_lp = r_ep + k;
+            if (tid < k) {
+                const int sx = cur[tid];
+                oth[r_rest[tid]] = sx < k ? (int)r_rest[sx] : (int)r_cyc[r_lp[tid]];
+            }
+            if (tid < c) oth[r_cyc[tid]] = r_hd[r_cyc[tid]];
+            __syncthreads();
+            if (tid == 0) {
+                const int mh = cur[k];
+                oth[r_cyc[r_ep[mh]]] = r_rest[mh];
+            }
+            __syncthreads();
+            int *t = cur; cur = oth; oth = t;
+        }
+        // `cur` now holds the tree over the original l nodes
+        // -------------------------------------------------------------- single-root logic (ref :137-169)
+        if (root < 0) {
+            if (tid == 0) { sc[SC_NROOT] = 0; sc[SC_NEXT] = INT_MAX; }
+            __syncthreads();
+            if (tid < l) {
+                tree0[tid] = cur[tid];
+                if (tid >= 1 && cur[tid] == 0) { atomicAdd(&sc[SC_NROOT], 1); atomicMin(&sc[SC_NEXT], tid); }
+            }
+            __syncthreads();
+            if (sc[SC_NROOT] == 1) {
+                if (tid < l) hout[tid] = cur[tid];
+                if (tid == 0) a.status[b] = PHONLP_MST_OK;
+                return;
+            }
+        } else {
+            // tree_probs = _scores[arange, _tree] on the EDITED top-level matrix (ref :157)
+            if (tid == 0) sc[SC_FINITE] = 1;
+            __syncthreads();
+            if (tid < l) {
+                const int i = tid, j = cur[tid];
+                double v;
+                if (i == 0 || i == root) v = j == 0 ? 0.0 : NEG_INF_D;
+                else if (j == 0 || j == i) v = NEG_INF_D;
+                else v = (double)arc[(long)i * L + j];
+                edge[i] = v;
+                if (!(v > NEG_INF_D)) sc[SC_FINITE] = 0;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                double score = NEG_INF_D;
+                if (sc[SC_FINITE]) score = np_sum<4>(edge, l) + (double)arc[(long)root * L];
+                dsc[1] = score;
+            }
+            __syncthreads();
+            const double score = dsc[1];
+            if (score > best_score) {  // strict: the first best candidate wins (ref :159)
+                best_score = score;
+                have_best = 1;
+                if (tid < l) besttree[tid] = cur[tid];
+            }
+            if (tid == 0) sc[SC_NEXT] = INT_MAX;
+            __syncthreads();
+            if (tid < l && tid > root && tree0[tid] == 0) atomicMin(&sc[SC_NEXT], tid);
+            __syncthreads();
+        }
+        const int next = sc[SC_NEXT];
+        __syncthreads();
+        if (next == INT_MAX) break;
+        root = next;
+    }
+    if (err) {
+        if (tid == 0) a.status[b] = 2;
+        return;
+    }
+    if (have_best) {
+        if (tid < l) hout[tid] = besttree[tid];
+        if (tid == 0) a.status[b] = PHONLP_MST_OK;
+    } else if (tid == 0) {
+        a.status[b] = PHONLP_MST_NO_FINITE_TREE;
+    }
+#undef SM
+}
+
+static size_t mst_aux_bytes(int L) { return (size_t)L * 8 * 3 + 32 + (size_t)L * 4 * 17 + (SC_COUNT + 16) * 4; }
+static int mst_pitch(int L) { return L | 1; }
+static bool mst_fits_lds(int L) { return (size_t)L * mst_pitch(L) * 8 + mst_aux_bytes(L) <= 160 * 1024; }
+static int mst_lvl_stride(int L) { return 4 * L + 8; }
+
+}  // namespace phonlp
+
+using namespace phonlp;
+
+extern "C" size_t phonlp_mst_ws_bytes(int B, int L) {
+    size_t bytes = align_up((size_t)B * L * mst_lvl_stride(L) * sizeof(uint16_t), 256);
+    if (!mst_fits_lds(L)) bytes += align_up((size_t)B * L * mst_pitch(L) * sizeof(double), 256);
+    return bytes;
+}
+
+extern "C" int phonlp_mst_one_root(const float *arc, const int32_t *sentlens, int B, int L, int32_t *heads,
+                                   int32_t *status, void *ws, size_t ws_bytes, void *stream) {
+    if (!arc || !sentlens || !heads || !status || B <= 0 || L <= 0)
+        return fail(PHONLP_ERR_SHAPE, "mst_one_root: bad argument");
+    if (L > 1024) return fail(PHONLP_ERR_UNSUPPORTED, "mst_one_root: L > 1024 (one thread per node)");
+    if (!ws || ws_bytes < phonlp_mst_ws_bytes(B, L)) return fail(PHONLP_ERR_WORKSPACE, "mst_one_root: workspace too small");
+    MstArgs a{};
+    a.arc = arc; a.sentlens = sentlens; a.heads = heads; a.status = status;
+    a.stack = (uint16_t *)ws;
+    a.lvl_stride = mst_lvl_stride(L);
+    a.stack_stride = (long)L * a.lvl_stride;
+    a.B = B; a.L = L; a.pitch = mst_pitch(L);
+    const bool in_lds = mst_fits_lds(L);
+    const int threads = L <= 256 ? 256 : (L + 63) / 64 * 64;
+    size_t lds = mst_aux_bytes(L);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)mst_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+                hipSuccess ||
+            hipFuncSetAttribute((const void *)mst_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+                hipSuccess)
+            return fail(PHONLP_ERR_LAUNCH, "mst_one_root: cannot raise the dynamic LDS limit");
+        attr_set = true;
+    }
+    if (in_lds) {
+        lds += (size_t)L * a.pitch * sizeof(double);
+        hipLaunchKernelGGL(mst_kernel<true>, dim3(B), dim3(threads), lds, as_stream(stream), a);
+    } else {
+        a.gmat = (double *)((char *)ws + align_up((size_t)B * L * a.lvl_stride * sizeof(uint16_t), 256));
+        a.gmat_stride = (long)L * a.pitch;
+        hipLaunchKernelGGL(mst_kernel<false>, dim3(B), dim3(threads), lds, as_stream(stream), a);
+    }
+    return check_launch("mst_kernel");
+}

@@ -1,0 +1,149 @@
+"""Host-side mirror of the reference's head modules, running on the HIP kernels.
+
+`HeadWeights` takes the reference's own `state_dict` names (ref
+annotate_model.py:34-100) and packs them once into the layouts the kernels read.  `TaskHeads`
+exposes the two forward seams (`tagger` ~ JointModel.tagger_forward, `parser` ~ JointModel.dep_forward,
+both starting AFTER the first-subword gather) and the decoders, everything staying on the device.
+"""
+from dataclasses import dataclass
+from typing import Dict, Optional, Sequence, Union
+
+import torch
+
+from . import ops
+
+SCORERS = ("unlabeled", "linearization", "distance")
+
+
+def as_sentlens(sentlens: Union[Sequence[int], torch.Tensor], device) -> torch.Tensor:
+    if isinstance(sentlens, torch.Tensor):
+        return sentlens.to(device=device, dtype=torch.int32).contiguous()
+    return torch.tensor(list(sentlens), dtype=torch.int32, device=device)
+
+
+@dataclass
+class HeadWeights:
+    """Device-resident head parameters in kernel layout."""
+    upos_hid_w: torch.Tensor
+    upos_hid_b: torch.Tensor
+    upos_clf_w: torch.Tensor
+    upos_clf_b: torch.Tensor
+    emb_ner: torch.Tensor
+    emb_dep: torch.Tensor
+    ner_w: torch.Tensor
+    ner_b: torch.Tensor
+    trans: torch.Tensor
+    dep_hid_w: torch.Tensor
+    dep_hid_b: torch.Tensor
+    arc_W12: torch.Tensor
+    arc_b12: torch.Tensor
+    arc_Wbt: torch.Tensor
+    lab_W12: torch.Tensor
+    lab_b12: torch.Tensor
+    lab_Wbt: torch.Tensor
+    H: int
+    O: int
+    n_arc_scorers: int
+    linearization: bool
+    distance: bool
+
+    @classmethod
+    def from_state_dict(cls, sd: Dict[str, torch.Tensor], device="cuda", linearization=True, distance=True):
+        """`sd`: the reference checkpoint's `model` dict (or `JointModel.state_dict()`); encoder keys are
+        ignored.  `linearization` / `distance` are the reference's `args` flags (annotate_model.py:77-94)."""
+        def g(name):
+            return sd[name].detach().to(device=device, dtype=torch.float32).contiguous()
+
+        def pack(name):
+            return ops.pack_scorer(g(f"{name}.W1.weight"), g(f"{name}.W1.bias"), g(f"{name}.W2.weight"),
+                                   g(f"{name}.W2.bias"), g(f"{name}.scorer.W_bilin.weight"))
+
+        H = sd["unlabeled.W1.weight"].shape[0]
+        O = sd["deprel.scorer.W_bilin.weight"].shape[2]
+        if linearization or distance:
+            # the arc kernel keeps one slot per scorer; a disabled scorer gets zero weights and is ignored
+            packs = []
+            for name, on in zip(SCORERS, (True, linearization, distance)):
+                if on:
+                    packs.append(pack(name))
+                else:
+                    packs.append(tuple(torch.zeros_like(t) for t in packs[0]))
+            arc = tuple(torch.cat([p[k] for p in packs], 0).contiguous() for k in range(3))
+            n_arc = 3
+        else:
+            arc = pack("unlabeled")
+            n_arc = 1
+        lab = pack("deprel")
+        return cls(
+            upos_hid_w=g("upos_hid.weight"), upos_hid_b=g("upos_hid.bias"),
+            upos_clf_w=g("upos_clf.weight"), upos_clf_b=g("upos_clf.bias"),
+            emb_ner=g("upos_emb_matrix_ner"), emb_dep=g("upos_emb_matrix_dep"),
+            ner_w=g("ner_tag_clf.weight"), ner_b=g("ner_tag_clf.bias"),
+            trans=g("crit_ner._transitions"),
+            dep_hid_w=g("dep_hid.weight"), dep_hid_b=g("dep_hid.bias"),
+            arc_W12=arc[0], arc_b12=arc[1], arc_Wbt=arc[2],
+            lab_W12=lab[0], lab_b12=lab[1], lab_Wbt=lab[2],
+            H=H, O=O, n_arc_scorers=n_arc, linearization=bool(linearization), distance=bool(distance),
+        )
+
+
+class TaskHeads:
+    """POS + NER + dependency heads on the GPU.  All inputs/outputs are device tensors."""
+
+    def __init__(self, weights: HeadWeights):
+        self.w = weights
+
+    # ---- JointModel.tagger_forward after the gather (ref annotate_model.py:132-152)
+    def tagger(self, enc: torch.Tensor, sentlens) -> Dict[str, torch.Tensor]:
+        w = self.w
+        lens = as_sentlens(sentlens, enc.device)
+        feat, pos_pred, upos_logits = ops.pos_head(enc.contiguous(), lens, w.upos_hid_w, w.upos_hid_b, w.upos_clf_w,
+                                                   w.upos_clf_b, w.emb_ner)
+        ner_logits = ops.ner_emission(feat, lens, w.ner_w, w.ner_b)
+        return {"pos_pred": pos_pred, "ner_logits": ner_logits, "upos_logits": upos_logits, "feat": feat,
+                "sentlens": lens}
+
+    # ---- JointModel.dep_forward after the gather (ref annotate_model.py:172-215)
+    def parser(self, enc: torch.Tensor, sentlens, want_raw=False, want_label_scores=False) -> Dict[str, torch.Tensor]:
+        w = self.w
+        lens = as_sentlens(sentlens, enc.device)
+        feat, _, upos_logits = ops.pos_head(enc.contiguous(), lens, w.upos_hid_w, w.upos_hid_b, w.upos_clf_w,
+                                            w.upos_clf_b, w.emb_dep)
+        hidden = ops.dep_hidden(feat, lens, w.dep_hid_w, w.dep_hid_b)
+        arc_logp, raw = ops.deep_biaffine_arc(hidden, w.arc_W12, w.arc_b12, w.arc_Wbt, w.H, w.n_arc_scorers,
+                                              w.linearization, w.distance, want_raw)
+        label_argmax, label_scores = ops.deep_biaffine_label(hidden, w.lab_W12, w.lab_b12, w.lab_Wbt, w.H, w.O,
+                                                             want_label_scores)
+        out = {"arc_logp": arc_logp, "label_argmax": label_argmax, "hidden_out": hidden, "upos_logits": upos_logits,
+               "feat": feat, "sentlens": lens}
+        if want_raw:
+            out["raw"] = raw
+        if want_label_scores:
+            out["label_scores"] = label_scores  # [B, L, O, L] -- the reference's memory order (biaffine.py:35)
+        return out
+
+    # ---- decoders
+    def viterbi(self, ner_logits: torch.Tensor, sentlens):
+        lens = as_sentlens(sentlens, ner_logits.device)
+        return ops.crf_viterbi(ner_logits.contiguous(), self.w.trans, lens)
+
+    def mst(self, arc_logp: torch.Tensor, sentlens):
+        lens = as_sentlens(sentlens, arc_logp.device)
+        return ops.mst_one_root(arc_logp.contiguous(), lens)
+
+    def crf_log_partition(self, ner_logits, pad_mask=None, sentlens=None, gold=None):
+        dev = ner_logits.device
+        pm = None if pad_mask is None else pad_mask.to(device=dev, dtype=torch.uint8).contiguous()
+        ln = None if sentlens is None else as_sentlens(sentlens, dev)
+        gd = None if gold is None else gold.to(device=dev, dtype=torch.int32).contiguous()
+        return ops.crf_log_partition(ner_logits.contiguous(), self.w.trans, pm, ln, gd)
+
+    # ---- the whole head path for one batch: what annotate() needs per batch (ref :256-287)
+    def annotate_batch(self, enc_dep, sentlens_dep, enc_tag, sentlens_tag) -> Dict[str, torch.Tensor]:
+        """Returns device int32 tensors: pos [B,Lt], ner [B,Lt], heads [B,Ld], rels [B,Ld], mst_status [B]."""
+        dep = self.parser(enc_dep, sentlens_dep)
+        tag = self.tagger(enc_tag, sentlens_tag)
+        ner, _ = ops.crf_viterbi(tag["ner_logits"], self.w.trans, tag["sentlens"])
+        heads, status = ops.mst_one_root(dep["arc_logp"], dep["sentlens"])
+        rels = ops.gather_labels(dep["label_argmax"], heads, dep["sentlens"])
+        return {"pos": tag["pos_pred"], "ner": ner, "heads": heads, "rels": rels, "mst_status": status}

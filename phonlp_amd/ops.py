@@ -1,0 +1,211 @@
+"""PyTorch-ROCm custom ops (`torch.ops.phonlp_amd.*`) over the C-ABI of libphonlp_heads.so.
+
+Each op allocates its outputs (and scratch) with torch's ROCm caching allocator, then enqueues the
+hand-written HIP kernels on torch's current stream through ctypes.  PyTorch is plumbing here: device
+memory and streams only -- none of the arithmetic of the task heads is done by torch operators.
+"""
+import ctypes
+from typing import Optional, Tuple
+
+import torch
+
+from ._lib import check, lib
+
+Tensor = torch.Tensor
+
+
+def _p(t: Optional[Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need(t: Tensor, dtype, name: str):
+    if not t.is_cuda:
+        raise ValueError(f"{name}: expected a ROCm device tensor (phonlp_amd has no CPU path)")
+    if t.dtype != dtype:
+        raise ValueError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: expected a contiguous tensor")
+
+
+def _ws(nbytes: int, device) -> Tensor:
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def kp(H: int) -> int:
+    return lib().phonlp_kp(H)
+
+
+@torch.library.custom_op("phonlp_amd::linear", mutates_args=())
+def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor], relu: bool, sentlens: Optional[Tensor], L: int) -> Tensor:
+    """y = act(x @ weight.T + bias); rows (b,i) with i >= sentlens[b] are zeroed when sentlens is given."""
+    _need(x, torch.float32, "x")
+    _need(weight, torch.float32, "weight")
+    M, K = x.shape
+    N = weight.shape[0]
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    check(lib().phonlp_linear(_p(x), K, _p(weight), K, _p(bias), _p(y), N, M, N, K, int(relu), _p(sentlens), L,
+                              _stream()), "phonlp_linear")
+    return y
+
+
+@torch.library.custom_op("phonlp_amd::pack_scorer", mutates_args=())
+def pack_scorer(W1: Tensor, b1: Tensor, W2: Tensor, b2: Tensor, Wbil: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+    """DeepBiaffineScorer parameters -> (W12 [2KP,D], b12 [2KP], Wbt [O*KP,KP]) in the kernels' layout."""
+    for n, t in (("W1", W1), ("b1", b1), ("W2", W2), ("b2", b2), ("Wbil", Wbil)):
+        _need(t, torch.float32, n)
+    H, D = W1.shape
+    O = Wbil.shape[2]
+    if Wbil.shape[0] != H + 1 or Wbil.shape[1] != H + 1:
+        raise ValueError("W_bilin.weight must be (H+1, H+1, O)")
+    KP = kp(H)
+    W12 = torch.empty((2 * KP, D), dtype=torch.float32, device=W1.device)
+    b12 = torch.empty((2 * KP,), dtype=torch.float32, device=W1.device)
+    Wbt = torch.empty((O * KP, KP), dtype=torch.float32, device=W1.device)
+    check(lib().phonlp_pack_scorer_linear(_p(W1), _p(b1), _p(W2), _p(b2), H, D, _p(W12), _p(b12), _stream()),
+          "phonlp_pack_scorer_linear")
+    check(lib().phonlp_pack_bilinear(_p(Wbil), H, O, _p(Wbt), _stream()), "phonlp_pack_bilinear")
+    return W12, b12, Wbt
+
+
+@torch.library.custom_op("phonlp_amd::pos_head", mutates_args=())
+def pos_head(enc: Tensor, sentlens: Tensor, Whid: Tensor, bhid: Tensor, Wclf: Tensor, bclf: Tensor,
+             emb: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+    """enc [B,L,E] -> (feat [B,L,E+TE], pos_pred int32 [B,L], upos_logits [B,L,U])."""
+    _need(enc, torch.float32, "enc")
+    _need(sentlens, torch.int32, "sentlens")
+    B, L, E = enc.shape
+    H, U, TE = Whid.shape[0], Wclf.shape[0], emb.shape[1]
+    dev = enc.device
+    feat = torch.empty((B, L, E + TE), dtype=torch.float32, device=dev)
+    pos = torch.empty((B, L), dtype=torch.int32, device=dev)
+    logits = torch.empty((B, L, U), dtype=torch.float32, device=dev)
+    nb = lib().phonlp_pos_head_ws_bytes(B, L, E, H, U, TE)
+    ws = _ws(nb, dev)
+    check(lib().phonlp_pos_head(_p(enc), E, _p(sentlens), B, L, E, _p(Whid), _p(bhid), _p(Wclf), _p(bclf), _p(emb),
+                                H, U, TE, _p(feat), _p(pos), _p(logits), _p(ws), nb, _stream()), "phonlp_pos_head")
+    return feat, pos, logits
+
+
+@torch.library.custom_op("phonlp_amd::ner_emission", mutates_args=())
+def ner_emission(feat: Tensor, sentlens: Tensor, Wner: Tensor, bner: Tensor) -> Tensor:
+    _need(feat, torch.float32, "feat")
+    _need(sentlens, torch.int32, "sentlens")
+    B, L, D = feat.shape
+    T = Wner.shape[0]
+    out = torch.empty((B, L, T), dtype=torch.float32, device=feat.device)
+    check(lib().phonlp_ner_emission(_p(feat), D, _p(sentlens), B, L, _p(Wner), _p(bner), T, _p(out), _stream()),
+          "phonlp_ner_emission")
+    return out
+
+
+@torch.library.custom_op("phonlp_amd::dep_hidden", mutates_args=())
+def dep_hidden(feat: Tensor, sentlens: Tensor, Wdep: Tensor, bdep: Tensor) -> Tensor:
+    _need(feat, torch.float32, "feat")
+    _need(sentlens, torch.int32, "sentlens")
+    B, L, D = feat.shape
+    out = torch.empty((B, L, D), dtype=torch.float32, device=feat.device)
+    check(lib().phonlp_dep_hidden(_p(feat), D, _p(sentlens), B, L, _p(Wdep), _p(bdep), _p(out), _stream()),
+          "phonlp_dep_hidden")
+    return out
+
+
+@torch.library.custom_op("phonlp_amd::deep_biaffine_arc", mutates_args=())
+def deep_biaffine_arc(hidden: Tensor, W12: Tensor, b12: Tensor, Wbt: Tensor, H: int, n_scorers: int, use_lin: bool,
+                      use_dist: bool, want_raw: bool) -> Tuple[Tensor, Tensor]:
+    """hidden [B,L,D] -> (arc log-probs [B,L,L], raw scorer outputs [3,B,L,L] or an empty tensor)."""
+    _need(hidden, torch.float32, "hidden")
+    B, L, D = hidden.shape
+    dev = hidden.device
+    out = torch.empty((B, L, L), dtype=torch.float32, device=dev)
+    raw = torch.zeros((3, B, L, L), dtype=torch.float32, device=dev) if want_raw else torch.empty(0, device=dev)
+    nb = lib().phonlp_biaffine_arc_ws_bytes(B, L, H, n_scorers)
+    ws = _ws(nb, dev)
+    check(lib().phonlp_deep_biaffine_arc(_p(hidden), D, B, L, H, n_scorers, int(use_lin), int(use_dist), _p(W12),
+                                         _p(b12), _p(Wbt), _p(out), _p(raw) if want_raw else None, _p(ws), nb,
+                                         _stream()), "phonlp_deep_biaffine_arc")
+    return out, raw
+
+
+@torch.library.custom_op("phonlp_amd::deep_biaffine_label", mutates_args=())
+def deep_biaffine_label(hidden: Tensor, W12: Tensor, b12: Tensor, Wbt: Tensor, H: int, O: int,
+                        want_scores: bool) -> Tuple[Tensor, Tensor]:
+    """hidden [B,L,D] -> (label arg-max int32 [B,L,L], scores [B,L,O,L] or an empty tensor)."""
+    _need(hidden, torch.float32, "hidden")
+    B, L, D = hidden.shape
+    dev = hidden.device
+    out = torch.empty((B, L, L), dtype=torch.int32, device=dev)
+    scores = torch.empty((B, L, O, L), dtype=torch.float32, device=dev) if want_scores else torch.empty(0, device=dev)
+    nb = lib().phonlp_biaffine_label_ws_bytes(B, L, H, O)
+    ws = _ws(nb, dev)
+    check(lib().phonlp_deep_biaffine_label(_p(hidden), D, B, L, H, O, _p(W12), _p(b12), _p(Wbt), _p(out),
+                                           _p(scores) if want_scores else None, _p(ws), nb, _stream()),
+          "phonlp_deep_biaffine_label")
+    return out, scores
+
+
+@torch.library.custom_op("phonlp_amd::crf_viterbi", mutates_args=())
+def crf_viterbi(logits: Tensor, trans: Tensor, sentlens: Tensor) -> Tuple[Tensor, Tensor]:
+    """logits [B,L,T], trans [T,T] (prev, cur), sentlens int32 [B] -> (tags int32 [B,L], best score [B])."""
+    _need(logits, torch.float32, "logits")
+    _need(trans, torch.float32, "trans")
+    _need(sentlens, torch.int32, "sentlens")
+    B, L, T = logits.shape
+    tags = torch.empty((B, L), dtype=torch.int32, device=logits.device)
+    best = torch.empty((B,), dtype=torch.float32, device=logits.device)
+    check(lib().phonlp_crf_viterbi(_p(logits), _p(trans), _p(sentlens), B, L, T, _p(tags), _p(best), _stream()),
+          "phonlp_crf_viterbi")
+    return tags, best
+
+
+@torch.library.custom_op("phonlp_amd::crf_log_partition", mutates_args=())
+def crf_log_partition(logits: Tensor, trans: Tensor, pad_mask: Optional[Tensor], sentlens: Optional[Tensor],
+                      gold: Optional[Tensor]) -> Tuple[Tensor, Tensor, Tensor]:
+    """-> (log_norm [B], unary [B], binary [B]); unary/binary are zeros unless gold tags (int32) are given."""
+    _need(logits, torch.float32, "logits")
+    _need(trans, torch.float32, "trans")
+    B, L, T = logits.shape
+    dev = logits.device
+    if pad_mask is not None:
+        _need(pad_mask, torch.uint8, "pad_mask")
+    if sentlens is not None:
+        _need(sentlens, torch.int32, "sentlens")
+    if gold is not None:
+        _need(gold, torch.int32, "gold")
+    log_norm = torch.empty((B,), dtype=torch.float32, device=dev)
+    unary = torch.zeros((B,), dtype=torch.float32, device=dev)
+    binary = torch.zeros((B,), dtype=torch.float32, device=dev)
+    check(lib().phonlp_crf_log_partition(_p(logits), _p(trans), _p(pad_mask), _p(sentlens), _p(gold), B, L, T,
+                                         _p(log_norm), _p(unary), _p(binary), _stream()), "phonlp_crf_log_partition")
+    return log_norm, unary, binary
+
+
+@torch.library.custom_op("phonlp_amd::mst_one_root", mutates_args=())
+def mst_one_root(arc: Tensor, sentlens: Tensor) -> Tuple[Tensor, Tensor]:
+    """arc [B,L,L] log-probs (rows = dependents), sentlens int32 [B] -> (heads int32 [B,L], status int32 [B])."""
+    _need(arc, torch.float32, "arc")
+    _need(sentlens, torch.int32, "sentlens")
+    B, L, _ = arc.shape
+    dev = arc.device
+    heads = torch.empty((B, L), dtype=torch.int32, device=dev)
+    status = torch.empty((B,), dtype=torch.int32, device=dev)
+    nb = lib().phonlp_mst_ws_bytes(B, L)
+    ws = _ws(nb, dev)
+    check(lib().phonlp_mst_one_root(_p(arc), _p(sentlens), B, L, _p(heads), _p(status), _p(ws), nb, _stream()),
+          "phonlp_mst_one_root")
+    return heads, status
+
+
+@torch.library.custom_op("phonlp_amd::gather_labels", mutates_args=())
+def gather_labels(label_argmax: Tensor, heads: Tensor, sentlens: Tensor) -> Tensor:
+    _need(label_argmax, torch.int32, "label_argmax")
+    _need(heads, torch.int32, "heads")
+    _need(sentlens, torch.int32, "sentlens")
+    B, L = heads.shape
+    rels = torch.empty((B, L), dtype=torch.int32, device=heads.device)
+    check(lib().phonlp_gather_labels(_p(label_argmax), _p(heads), _p(sentlens), B, L, _p(rels), _stream()),
+          "phonlp_gather_labels")
+    return rels

@@ -1,0 +1,59 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds, loads and exports exactly the symbols
+include/phonlp_heads.h declares; argument validation that needs no GPU returns the documented error codes."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def heads_lib():
+    from phonlp_amd import build as B
+    from phonlp_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        B.build()
+    return _lib.lib()
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "phonlp_heads.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(phonlp_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported(heads_lib):
+    from phonlp_amd import _lib
+    names = declared_symbols()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(heads_lib, n), f"{n} declared in include/phonlp_heads.h but not exported"
+    assert sorted(_lib.SIGNATURES) == names, "ctypes table and header disagree"
+
+
+def test_kp_and_version(heads_lib):
+    assert heads_lib.phonlp_kp(400) == 416  # 400 features + ones column, padded to 32
+    assert heads_lib.phonlp_kp(16) == 32
+    assert heads_lib.phonlp_version() >= 100
+
+
+def test_argument_errors_without_gpu(heads_lib):
+    # NULL pointers / bad shapes are rejected before any HIP call
+    assert heads_lib.phonlp_crf_viterbi(None, None, None, 1, 1, 1, None, None, None) == -1
+    assert b"crf_viterbi" in heads_lib.phonlp_last_error()
+    assert heads_lib.phonlp_mst_one_root(None, None, 0, 0, None, None, None, 0, None) == -1
+    one = ctypes.c_void_p(16)
+    assert heads_lib.phonlp_crf_viterbi(one, one, one, 1, 4, 65, one, None, None) == -4  # T > 64 unsupported
+    assert heads_lib.phonlp_linear(one, 6, one, 6, None, one, 4, 2, 2, 6, 0, None, 0, None) == -1  # K % 4 != 0
+    assert heads_lib.phonlp_mst_ws_bytes(256, 128) > 0
+    assert heads_lib.phonlp_biaffine_label_ws_bytes(256, 128, 400, 33) == 256 * 128 * (2 * 416 + 33 * 416) * 4
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from phonlp_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libphonlp_heads.so")
+    with pytest.raises(_lib.HeadsLibraryError):
+        _lib.lib()

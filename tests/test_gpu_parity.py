@@ -1,0 +1,350 @@
+"""GPU parity tests: the HIP path (through the C-ABI, via the torch custom ops) against the CPU oracle,
+the reference-generated golden fixtures, and size-independent properties at the headline sizes.
+
+Bars (BASELINE.json north_star): decoded heads / relations / POS / NER tags bit-exact; arc and label
+scores and the CRF log-partition within 1e-3 relative in fp32 (the tolerances below are tighter).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import c_oracle as C  # noqa: E402
+from oracle import heads_oracle as O  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from phonlp_amd import _lib
+    _lib.lib()  # fail loudly if the HIP library is missing
+    C.build()
+    return torch.device("cuda:0")
+
+
+def _params(z, prefix="p_"):
+    return {k[len(prefix):]: torch.from_numpy(z[k]) for k in z.files if k.startswith(prefix)}
+
+
+def _close(got, want, rtol=2e-4, atol=2e-5):
+    got, want = torch.as_tensor(got).float().cpu(), torch.as_tensor(want).float().cpu()
+    fin = torch.isfinite(want)
+    assert torch.equal(fin, torch.isfinite(got)), "non-finite pattern differs"
+    torch.testing.assert_close(got[fin], want[fin], rtol=rtol, atol=atol)
+
+
+# ------------------------------------------------------------------------------------------ dense layer
+@pytest.mark.parametrize("M,N,K,relu,masked", [
+    (300, 70, 868, True, False), (129, 9, 868, True, True), (64, 416, 416, False, False),
+    (1000, 868, 868, False, True), (257, 24, 400, False, True), (128, 128, 32, True, False), (5, 3, 4, False, False),
+])
+def test_linear_vs_torch_fp32(dev, M, N, K, relu, masked):
+    from phonlp_amd import ops
+    g = torch.Generator().manual_seed(M * 7 + N)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    L = 50
+    B = (M + L - 1) // L
+    lens = torch.randint(1, L + 1, (B,), generator=g).to(torch.int32)
+    ref = x @ w.t() + b
+    if relu:
+        ref = torch.relu(ref)
+    if masked:
+        rows = torch.arange(M)
+        ref = ref * ((rows % L) < lens[rows // L].long()).unsqueeze(1)
+    got = ops.linear(x.to(dev), w.to(dev), b.to(dev), relu, lens.to(dev) if masked else None, L if masked else 0)
+    torch.testing.assert_close(got.cpu(), ref, rtol=1e-4, atol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------ Viterbi
+def test_viterbi_golden_bit_exact(dev, golden):
+    from phonlp_amd import ops
+    z = golden("viterbi.npz")
+    for c in range(int(z["n"])):
+        s, tr = z[f"v{c}_scores"], z[f"v{c}_trans"]
+        l, T = s.shape
+        logits = torch.zeros(2, l + 3, T)  # padded batch: second sentence is shorter
+        logits[0, :l] = torch.from_numpy(s)
+        logits[1, :max(l - 1, 1)] = torch.from_numpy(s[:max(l - 1, 1)])
+        lens = torch.tensor([l, max(l - 1, 1)], dtype=torch.int32)
+        tags, best = ops.crf_viterbi(logits.to(dev), torch.from_numpy(tr).to(dev), lens.to(dev))
+        assert tags[0, :l].cpu().tolist() == z[f"v{c}_tags"].tolist(), f"case {c}"
+        assert tags[0, l:].abs().sum().item() == 0
+        assert np.float32(best[0].item()) == z[f"v{c}_best"], f"case {c}"
+        want1, b1 = O.viterbi_decode(s[:max(l - 1, 1)], tr)
+        assert tags[1, :max(l - 1, 1)].cpu().tolist() == want1 and np.float32(best[1].item()) == np.float32(b1)
+
+
+@pytest.mark.parametrize("B,L,T,mode", [(256, 128, 9, "relu"), (64, 127, 12, "relu_zero"), (33, 300, 40, "rand"),
+                                        (7, 1, 9, "rand"), (256, 127, 9, "ints")])
+def test_viterbi_random_vs_c_oracle(dev, B, L, T, mode):
+    from phonlp_amd import ops
+    rng = np.random.default_rng(B + L + T)
+    x = rng.standard_normal((B, L, T)).astype(np.float32)
+    tr = (rng.standard_normal((T, T)) * 0.1).astype(np.float32)
+    if mode.startswith("relu"):
+        x = np.maximum(x, 0)
+    if mode == "relu_zero":
+        tr[:] = 0
+    if mode == "ints":
+        x = rng.integers(-2, 3, (B, L, T)).astype(np.float32)
+        tr = rng.integers(-1, 2, (T, T)).astype(np.float32)
+    lens = np.sort(rng.integers(1, L + 1, B))[::-1].astype(np.int32).copy()
+    lens[0] = L
+    want_tags, want_best = C.viterbi_batch(x, tr, lens)
+    tags, best = ops.crf_viterbi(torch.from_numpy(x).to(dev), torch.from_numpy(tr).to(dev), torch.from_numpy(lens).to(dev))
+    assert np.array_equal(tags.cpu().numpy(), want_tags)
+    assert np.array_equal(best.cpu().numpy(), want_best)  # single fp32 adds: bit-exact
+
+
+# ------------------------------------------------------------------------------------------ CRF forward
+def test_crf_log_partition_golden(dev, golden):
+    from phonlp_amd import ops
+    z = golden("crf.npz")
+    for c in range(int(z["n"])):
+        x, m, t, tr = (torch.from_numpy(z[f"c{c}_{k}"]) for k in ("inputs", "masks", "tags", "trans"))
+        ln, un, bi = ops.crf_log_partition(x.to(dev), tr.to(dev), m.to(torch.uint8).to(dev), None,
+                                           t.to(torch.int32).to(dev))
+        torch.testing.assert_close(ln.cpu(), torch.from_numpy(z[f"c{c}_log_norm"]), rtol=1e-5, atol=1e-5)
+        loss = (-(un + bi - ln)).sum().item() / x.shape[0]
+        assert abs(loss - float(z[f"c{c}_loss"])) <= 1e-4 * max(1.0, abs(float(z[f"c{c}_loss"])))
+
+
+def test_crf_log_partition_random(dev):
+    from phonlp_amd import ops
+    rng = np.random.default_rng(5)
+    B, L, T = 256, 127, 9
+    x = np.maximum(rng.standard_normal((B, L, T)), 0).astype(np.float32)
+    tr = (rng.standard_normal((T, T)) * 0.1).astype(np.float32)
+    lens = np.sort(rng.integers(1, L + 1, B))[::-1].astype(np.int32).copy()
+    pad = (np.arange(L)[None, :] >= lens[:, None])
+    want = C.crf_log_norm(x, pad, tr)
+    ln, _, _ = ops.crf_log_partition(torch.from_numpy(x).to(dev), torch.from_numpy(tr).to(dev), None,
+                                     torch.from_numpy(lens).to(dev), None)
+    np.testing.assert_allclose(ln.cpu().numpy(), want, rtol=1e-5, atol=1e-4)
+    ln2, _, _ = ops.crf_log_partition(torch.from_numpy(x).to(dev), torch.from_numpy(tr).to(dev),
+                                      torch.from_numpy(pad.astype(np.uint8)).to(dev), None, None)
+    assert torch.equal(ln, ln2)  # mask form == sentlens form
+
+
+# ------------------------------------------------------------------------------------------ MST
+def _run_mst(dev, mats, L):
+    from phonlp_amd import ops
+    B = len(mats)
+    rng = np.random.default_rng(99)
+    arc = rng.standard_normal((B, L, L)).astype(np.float32)  # garbage outside [:l,:l] must be ignored
+    lens = np.zeros(B, np.int32)
+    for b, m in enumerate(mats):
+        l = m.shape[0]
+        arc[b, :l, :l] = m
+        lens[b] = l
+    heads, status = ops.mst_one_root(torch.from_numpy(arc).to(dev), torch.from_numpy(lens).to(dev))
+    torch.cuda.synchronize()
+    return heads.cpu().numpy(), status.cpu().numpy()
+
+
+def test_mst_golden_bit_exact(dev, golden):
+    z = golden("mst.npz")
+    mats, want = [], []
+    po = ph = 0
+    for l in z["sizes"]:
+        mats.append(z["flat"][po:po + l * l].reshape(l, l))
+        want.append(z["heads"][ph:ph + l])
+        po += l * l
+        ph += l
+    heads, status = _run_mst(dev, mats, 128)
+    assert (status == 0).all()
+    for k, (m, w) in enumerate(zip(mats, want)):
+        l = m.shape[0]
+        assert heads[k, :l].tolist() == w.tolist(), f"case {k} kind {z['kinds'][k]} l={l}"
+        assert not heads[k, l:].any()
+
+
+@pytest.mark.parametrize("B,L,kind", [(256, 128, "randn"), (128, 128, "rooty"), (128, 100, "ints"), (64, 128, "pairs"),
+                                      (24, 160, "randn"), (8, 300, "randn"), (6, 512, "randn")])
+def test_mst_random_vs_c_oracle(dev, B, L, kind):
+    rng = np.random.default_rng(B * 3 + L)
+    mats = []
+    for b in range(B):
+        l = L if b % 3 == 0 else int(rng.integers(2, L + 1))
+        if kind == "ints":
+            m = rng.integers(-3, 1, (l, l)).astype(np.float32)
+        else:
+            m = rng.standard_normal((l, l)) * 2
+            if kind == "rooty":
+                m[:, 0] += 3
+            if kind == "pairs":
+                for k in range(1, l - 1, 2):
+                    m[k, k + 1] += 4
+                    m[k + 1, k] += 4
+            m = m - np.log(np.exp(m).sum(1, keepdims=True))
+            m = m.astype(np.float32)
+        mats.append(m)
+    heads, status = _run_mst(dev, mats, L)
+    assert (status == 0).all()
+    for b, m in enumerate(mats):
+        want, rc = C.mst_one_root(m)
+        assert rc == 0
+        assert heads[b, :m.shape[0]].tolist() == want.tolist(), f"sentence {b} l={m.shape[0]}"
+
+
+def test_mst_root_only_sentence_reports_no_tree(dev):
+    heads, status = _run_mst(dev, [np.zeros((1, 1), np.float32), np.zeros((2, 2), np.float32)], 8)
+    assert status.tolist() == [1, 0]  # the reference asserts on l == 1 (chuliu_edmonds.py:162-168)
+    assert heads[1, :2].tolist() == [0, 0]
+
+
+# ------------------------------------------------------------------------------------------ biaffine fixtures
+def test_deep_biaffine_golden(dev, golden):
+    """DeepBiaffineScorer fixtures (reference output, incl. the flat-reshape quirk and the ignored bias)."""
+    from phonlp_amd import ops
+    z = golden("biaffine.npz")
+    for c in range(int(z["n_db"])):
+        p = _params(z, f"db{c}_p_")
+        h = torch.from_numpy(z[f"db{c}_h"])
+        B, L, D = h.shape
+        Dp = (D + 3) // 4 * 4  # the kernels need K % 4 == 0: zero-pad features and weight columns
+        pad = lambda t: torch.nn.functional.pad(t, (0, Dp - D))
+        W12, b12, Wbt = ops.pack_scorer(pad(p["W1.weight"]).to(dev), p["W1.bias"].to(dev), pad(p["W2.weight"]).to(dev),
+                                        p["W2.bias"].to(dev), p["scorer.W_bilin.weight"].contiguous().to(dev))
+        H = p["W1.weight"].shape[0]
+        O = p["scorer.W_bilin.weight"].shape[2]
+        ref = torch.from_numpy(z[f"db{c}_out"])  # B x L x L x O
+        _, scores = ops.deep_biaffine_label(pad(h).contiguous().to(dev), W12, b12, Wbt, H, O, True)
+        _close(scores.permute(0, 1, 3, 2), ref, rtol=1e-4, atol=1e-5)
+        if O == 1:
+            _, raw = ops.deep_biaffine_arc(pad(h).contiguous().to(dev), W12, b12, Wbt, H, 1, False, False, True)
+            _close(raw[0], ref.squeeze(3), rtol=1e-4, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------ whole head path
+@pytest.mark.parametrize("name", ["joint_small.npz", "joint_zero_init.npz"])
+def test_joint_fixture_end_to_end(dev, golden, name):
+    """The reference's own dep_forward / tagger_forward / decoders on a ragged batch (fixture made by running
+    annotate_model.JointModel) against the HIP path fed the same encoder rows."""
+    from phonlp_amd import HeadWeights, TaskHeads
+    z = golden(name)
+    heads = TaskHeads(HeadWeights.from_state_dict(_params(z), dev))
+    lens1, lens = z["dep_sentlens"].tolist(), z["tag_sentlens"].tolist()
+    dep = heads.parser(torch.from_numpy(z["dep_enc"]).to(dev), lens1)
+    tag = heads.tagger(torch.from_numpy(z["tag_enc"]).to(dev), lens)
+    _close(dep["arc_logp"], z["dep_arc_logp"], rtol=1e-4, atol=2e-5)
+    assert np.array_equal(dep["label_argmax"].cpu().numpy().astype(np.int64), z["dep_label_argmax"])
+    assert np.array_equal(tag["pos_pred"].cpu().numpy().astype(np.int64), z["tag_pos_pred"])
+    _close(tag["ner_logits"], z["tag_ner_logits"], rtol=1e-4, atol=1e-5)
+    # (a) tie semantics: decoders fed the REFERENCE's scores must reproduce the reference's decoded output
+    #     bit for bit (the zero-init fixture is all ties: heads come from the distance prior alone)
+    ref_arc = torch.from_numpy(z["dep_arc_logp"]).to(dev)
+    h_ref, st_ref = heads.mst(ref_arc, lens1)
+    assert (st_ref == 0).all()
+    got_heads = np.concatenate([h_ref[i, 1:l].cpu().numpy() for i, l in enumerate(lens1)])
+    assert got_heads.tolist() == z["dec_heads"].tolist()
+    from phonlp_amd import ops
+    rels_ref = ops.gather_labels(torch.from_numpy(z["dep_label_argmax"]).to(torch.int32).to(dev), h_ref,
+                                 torch.tensor(lens1, dtype=torch.int32, device=dev))
+    got_rels = np.concatenate([rels_ref[i, 1:l].cpu().numpy() for i, l in enumerate(lens1)])
+    assert got_rels.tolist() == z["dec_rels"].tolist()
+    ner_ref, _ = heads.viterbi(torch.from_numpy(z["tag_ner_logits"]).to(dev), lens)
+    got_ner = np.concatenate([ner_ref[i, :l].cpu().numpy() for i, l in enumerate(lens)])
+    assert got_ner.tolist() == z["dec_ner"].tolist()
+    # (b) end to end from the GPU's own scores.  Exact for the non-degenerate model; the zero-init model has
+    #     exact ties ACROSS rows on the CPU that fp32 rounding of the row normalisers may break either way.
+    out = heads.annotate_batch(torch.from_numpy(z["dep_enc"]).to(dev), lens1, torch.from_numpy(z["tag_enc"]).to(dev), lens)
+    assert (out["mst_status"] == 0).all()
+    if name == "joint_small.npz":
+        got_heads = np.concatenate([out["heads"][i, 1:l].cpu().numpy() for i, l in enumerate(lens1)])
+        got_rels = np.concatenate([out["rels"][i, 1:l].cpu().numpy() for i, l in enumerate(lens1)])
+        got_ner = np.concatenate([out["ner"][i, :l].cpu().numpy() for i, l in enumerate(lens)])
+        assert got_heads.tolist() == z["dec_heads"].tolist()
+        assert got_rels.tolist() == z["dec_rels"].tolist()
+        assert got_ner.tolist() == z["dec_ner"].tolist()
+    # CRF loss as predict_ner evaluates it
+    ln, un, bi = heads.crf_log_partition(torch.from_numpy(z["tag_ner_logits"]).to(dev),
+                                         pad_mask=torch.from_numpy(z["tag_words_mask"]),
+                                         gold=torch.from_numpy(z["crf_gold"]))
+    loss = (-(un + bi - ln)).sum().item() / len(lens)
+    assert abs(loss - float(z["crf_loss"])) <= 1e-4 * max(1.0, abs(float(z["crf_loss"])))
+
+
+def _near_tie_ok(got_idx, want_idx, scores, tol):
+    """Arg-max parity up to fp32 rounding: wherever the indices differ, the oracle's score at the GPU's
+    index must be within `tol` of the oracle's maximum (a genuine near-tie)."""
+    diff = got_idx != want_idx
+    if not diff.any():
+        return 0
+    top = scores.max(-1)[0]
+    at = torch.gather(scores, -1, got_idx.long().unsqueeze(-1)).squeeze(-1)
+    assert bool(((top - at)[diff] <= tol).all()), "arg-max differs where the oracle has a clear winner"
+    return int(diff.sum())
+
+
+@pytest.mark.parametrize("B,L,ragged", [(32, 64, False), (24, 128, True), (3, 200, True)])
+def test_synthetic_heads_vs_oracle(dev, B, L, ragged):
+    """BASELINE config 2 (B=32, L=64) and ragged / long variants with the 768/400/33/9 head sizes."""
+    from phonlp_amd import HeadWeights, TaskHeads
+    from phonlp_amd import synthetic as S
+    sd = S.make_state_dict()
+    enc_dep, enc_tag = S.make_encoder_outputs(B, L)
+    lens1 = S.make_sentlens(B, L, ragged)
+    lens = [l - 1 for l in lens1]
+    heads = TaskHeads(HeadWeights.from_state_dict(sd, dev))
+    dep = heads.parser(enc_dep.to(dev), lens1, want_raw=True, want_label_scores=True)
+    tag = heads.tagger(enc_tag.to(dev), lens)
+    od = O.dep_heads(enc_dep, lens1, sd)
+    ot = O.tagger_heads(enc_tag, lens, sd)
+    _close(dep["hidden_out"], od["hidden_out"], rtol=1e-4, atol=1e-5)
+    _close(dep["raw"][0], od["unlabeled_raw"], rtol=1e-3, atol=1e-4)
+    _close(dep["raw"][1], od["lin_raw"], rtol=1e-3, atol=1e-4)
+    _close(dep["raw"][2], od["dist_raw"], rtol=1e-3, atol=1e-4)
+    _close(dep["arc_logp"], od["arc_logp"], rtol=1e-3, atol=1e-4)
+    _close(dep["label_scores"].permute(0, 1, 3, 2), od["label_scores"], rtol=1e-3, atol=1e-4)
+    flips = _near_tie_ok(dep["label_argmax"].cpu(), od["label_argmax"], od["label_scores"], 1e-4)
+    assert flips <= 1e-4 * B * L * L
+    _close(tag["ner_logits"], ot["ner_logits"], rtol=1e-4, atol=1e-5)
+    _near_tie_ok(tag["pos_pred"].cpu(), ot["pos_pred"], ot["upos_logits"], 1e-5)
+    # decoders are bit-exact GIVEN the same scores: feed the GPU decoders the GPU scores and compare with
+    # the C oracle on those same scores
+    ner, best = heads.viterbi(tag["ner_logits"], lens)
+    wt, wb = C.viterbi_batch(tag["ner_logits"].cpu().numpy(), sd["crit_ner._transitions"].numpy(), lens)
+    assert np.array_equal(ner.cpu().numpy(), wt) and np.array_equal(best.cpu().numpy(), wb)
+    h, st = heads.mst(dep["arc_logp"], lens1)
+    wh, ws = C.mst_batch(dep["arc_logp"].cpu().numpy(), lens1)
+    assert np.array_equal(st.cpu().numpy(), ws) and np.array_equal(h.cpu().numpy(), wh)
+    # and end-to-end: trees decoded from GPU scores vs trees decoded from oracle scores
+    oh, _ = C.mst_batch(od["arc_logp"].numpy(), lens1)
+    assert (h.cpu().numpy() != oh).mean() <= 0.002
+
+
+def test_headline_batch_properties(dev):
+    """B=256, L=128 (BASELINE config 3): sentences are independent, so any sub-batch must reproduce the big
+    batch bit-for-bit; decoded trees must be single-rooted and acyclic; decoders match the C oracle."""
+    from phonlp_amd import HeadWeights, TaskHeads
+    from phonlp_amd import synthetic as S
+    B, L = 256, 128
+    sd = S.make_state_dict()
+    enc_dep, enc_tag = S.make_encoder_outputs(B, L)
+    lens1 = S.make_sentlens(B, L, False)
+    lens = [l - 1 for l in lens1]
+    heads = TaskHeads(HeadWeights.from_state_dict(sd, dev))
+    big = heads.annotate_batch(enc_dep.to(dev), lens1, enc_tag.to(dev), lens)
+    dep = heads.parser(enc_dep.to(dev), lens1)
+    sub = slice(40, 56)
+    small = heads.annotate_batch(enc_dep[sub].to(dev), lens1[sub], enc_tag[sub].to(dev), lens[sub])
+    for k in ("pos", "ner", "heads", "rels"):
+        assert torch.equal(big[k][sub], small[k]), k
+    assert (big["mst_status"] == 0).all()
+    h = big["heads"].cpu().numpy()
+    for b in range(B):
+        assert (h[b, 1:] == 0).sum() == 1  # exactly one child of ROOT
+        for i in range(1, L):  # every node reaches ROOT
+            v, steps = i, 0
+            while v != 0 and steps <= L:
+                v, steps = h[b, v], steps + 1
+            assert v == 0
+    wh, ws = C.mst_batch(dep["arc_logp"].cpu().numpy(), lens1)
+    assert np.array_equal(h, wh)
+    rel_want = np.take_along_axis(dep["label_argmax"].cpu().numpy(), h[:, :, None].astype(np.int64), 2)[:, :, 0]
+    rel_want[:, 0] = 0
+    assert np.array_equal(big["rels"].cpu().numpy(), rel_want)
