@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py -- sentences/sec through the POS + NER + dependency heads on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the whole head path over one synthetic batch (BASELINE.json config 3: B=256
+sentences, L=128 words incl. ROOT; encoder outputs already resident in HBM): POS head (both task passes),
+dep_hid, four deep-biaffine scorers with the fused arc epilogue + log-softmax and label arg-max, NER
+emissions + Viterbi, Chu-Liu-Edmonds single-root MST, relation lookup.  Output per sentence: POS ids, NER
+tags, heads, relation ids, left on the device.  Sentences are independent, so ranks each run their own
+batches (weak scaling, no data-path collective); the only collective is one all-reduce of the eval-count
+vector (RCCL) inside the timed region.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (bilinear stage A of the label
+scorer, an fp32 MFMA GEMM) timed live with HIP events on its launch stream; `cpu_baseline` is the CPU
+oracle (kind "port": torch-CPU GEMMs + per-sentence numpy decoders, the reference's structure) timed on
+this host on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+B, L, E, TE, H, U, O, T = 256, 128, 768, 100, 400, 24, 33, 9
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak
+PEAK_HBM_GBS = 8000.0
+
+
+def algorithmic_flops():
+    """SURVEY.md section 8(d) formulas, per sentence of parser length L (2*m*n*k)."""
+    D, H1 = E + TE, H + 1
+    per_scorer = lambda o: 4 * L * D * H + 2 * L * H1 * H1 * o + 2 * L * L * H1 * o
+    biaffine = 3 * per_scorer(1) + per_scorer(O)
+    dep_hid = 2 * L * D * D
+    pos = 2 * L * (E * H + H * U + U * TE) + 2 * (L - 1) * (E * H + H * U + U * TE)
+    ner = 2 * (L - 1) * D * T
+    return {"total": biaffine + dep_hid + pos + ner, "label_stage_a": 2 * L * H1 * H1 * O}
+
+
+def cpu_baseline(sd, enc_dep, enc_tag, lens_dep, lens_tag, n_sample=48):
+    """The oracle on this host: GEMM heads through torch CPU (all intra-op threads), decoders per sentence in
+    numpy exactly as the reference drives them (single thread)."""
+    from oracle import heads_oracle as Or
+    ed, et = enc_dep[:n_sample], enc_tag[:n_sample]
+    ld, lt = lens_dep[:n_sample], lens_tag[:n_sample]
+    with torch.no_grad():
+        Or.dep_heads(ed[:4], ld[:4], sd, keep_label_scores=False)  # warm-up
+        t0 = time.perf_counter()
+        dep = Or.dep_heads(ed, ld, sd, keep_label_scores=False)
+        tag = Or.tagger_heads(et, lt, sd)
+        t_gemm = time.perf_counter() - t0
+    arc = dep["arc_logp"].numpy()
+    n_mst = min(n_sample, 24)
+    t0 = time.perf_counter()
+    for i in range(n_mst):
+        Or.chuliu_edmonds_one_root(arc[i][:ld[i], :ld[i]])
+    t_mst = (time.perf_counter() - t0) / n_mst
+    logits, trans = tag["ner_logits"].numpy(), sd["crit_ner._transitions"].numpy()
+    t0 = time.perf_counter()
+    for i in range(n_sample):
+        Or.viterbi_decode(logits[i, :lt[i]], trans)
+    t_vit = (time.perf_counter() - t0) / n_sample
+    per_sentence = t_gemm / n_sample + t_mst + t_vit
+    return {
+        "value": 1.0 / per_sentence, "unit": "sentences/s", "cores": torch.get_num_threads(), "kind": "port",
+        "sample": f"{n_sample} of {B} sentences (L={L}) for the torch-CPU heads and Viterbi, {n_mst} for the numpy MST; "
+                  f"per-sentence seconds: heads {t_gemm / n_sample:.4f}, mst {t_mst:.4f}, viterbi {t_vit:.4f}; "
+                  f"decoders single-threaded as in the reference",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from phonlp_amd import HeadWeights, TaskHeads
+    from phonlp_amd import synthetic as S
+    from phonlp_amd.profile import KernelTimer
+
+    sd = S.make_state_dict(E, TE, H, U, O, T, seed=1234)
+    heads = TaskHeads(HeadWeights.from_state_dict(sd, dev))
+    # every rank draws its own shard of the synthetic corpus (seed offset by rank): weak scaling
+    enc_dep_h, enc_tag_h = S.make_encoder_outputs(B, L, E, seed=1234 + 1000 * rank)
+    lens_dep, lens_tag = [L] * B, [L - 1] * B
+    enc_dep, enc_tag = enc_dep_h.to(dev), enc_tag_h.to(dev)
+    ld = torch.tensor(lens_dep, dtype=torch.int32, device=dev)
+    lt = torch.tensor(lens_tag, dtype=torch.int32, device=dev)
+    g = torch.Generator().manual_seed(99 + rank)  # synthetic gold annotations for the eval counts
+    gold_pos = torch.randint(0, U, (B, L - 1), generator=g, dtype=torch.int32).to(dev)
+    gold_ner = torch.randint(0, T, (B, L - 1), generator=g, dtype=torch.int32).to(dev)
+    gold_head = torch.randint(0, L, (B, L), generator=g, dtype=torch.int32).to(dev)
+    gold_rel = torch.randint(0, O, (B, L), generator=g, dtype=torch.int32).to(dev)
+    counts = torch.zeros(8, dtype=torch.int64, device=dev)
+
+    def step():
+        out = heads.annotate_batch(enc_dep, ld, enc_tag, lt)
+        uas = (out["heads"][:, 1:] == gold_head[:, 1:])
+        counts[0] += B
+        counts[1] += B * (L - 1)
+        counts[2] += (out["pos"] == gold_pos).sum()
+        counts[3] += (out["ner"] == gold_ner).sum()
+        counts[4] += uas.sum()
+        counts[5] += (uas & (out["rels"][:, 1:] == gold_rel[:, 1:])).sum()
+        counts[6] += (out["mst_status"] != 0).sum()
+        return out
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    counts.zero_()
+    kt = KernelTimer(max_samples=64 * args.steps)
+    kt.__enter__()  # creates the event pool before the timed region; 2 hipEventRecord per kernel inside it
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if dist is not None:
+        dist.all_reduce(counts)  # the only collective: eval counts over RCCL
+    fence()
+    elapsed = time.perf_counter() - t0
+    kt.__exit__(None, None, None)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        fl = algorithmic_flops()
+        sent = B * args.steps * world
+        c = counts.cpu().tolist()
+        assert c[0] == sent and c[6] == 0, f"eval counts inconsistent: {c}"
+        n, mean_ms, min_ms = kt.stats["linear:label_stage_a"]
+        achieved = fl["label_stage_a"] * B / (mean_ms * 1e-3) / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("linear:label_stage_a")
+        res = {
+            "metric": "sentences/sec through POS+NER+dep heads at B=256,L=128",
+            "value": sent / elapsed, "unit": "sentences/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE config 3: synthetic B=256 L=128 full heads incl. Chu-Liu-Edmonds MST "
+                                   "(E=768, H=400, n_rel=33, n_ner=9, n_upos=24), encoder outputs resident in HBM",
+                       "batch_per_gpu": B, "seq_len": L, "parallelism": f"sentence-sharded x{world}"},
+            "mfma_util_pct_whole_path": 100.0 * fl["total"] * B * args.steps / elapsed / (PEAK_F32_MFMA_TFLOPS * 1e12),
+            "roofline": {"kernel": "linear_kernel<128,128,2,2> as bilinear stage A of the label scorer",
+                         "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                         "launches_timed": n, "mean_ms": mean_ms, "min_ms": min_ms,
+                         "algorithmic_flops_per_launch": fl["label_stage_a"] * B},
+            "kernels_ms": {k: round(v[1], 4) for k, v in sorted(kt.stats.items())},
+            "eval_counts": {"sentences": c[0], "words": c[1], "pos_correct": c[2], "ner_correct": c[3],
+                            "uas_correct": c[4], "las_correct": c[5]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(sd, enc_dep_h, enc_tag_h, lens_dep, lens_tag)
+            res["speedup_vs_cpu_baseline"] = res["value"] / res["cpu_baseline"]["value"]
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

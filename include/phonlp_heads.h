@@ -153,6 +153,17 @@ int phonlp_mst_one_root(const float *arc, const int32_t *sentlens, int B, int L,
 int phonlp_gather_labels(const int32_t *label_argmax, const int32_t *heads, const int32_t *sentlens, int B, int L,
                          int32_t *rels, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Per-kernel timing (no counterpart in the reference, which has no profiling: SURVEY.md section 5).
+ * Between _begin and _end every kernel launch of the library is bracketed by a hipEvent pair recorded
+ * on its launch stream (up to max_samples launches).  _end synchronises those events and copies the
+ * durations (milliseconds) and a tag id per launch to HOST arrays; returns the number of samples or a
+ * negative error.  phonlp_profile_tag_name(id) names a tag ("linear:label_stage_a", "mst", ...).
+ */
+int phonlp_profile_begin(int max_samples);
+int phonlp_profile_end(float *ms_out_host, int32_t *tag_out_host, int cap);
+const char *phonlp_profile_tag_name(int id);
+
 #ifdef __cplusplus
 }
 #endif

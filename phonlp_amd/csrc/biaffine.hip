@@ -11,7 +11,7 @@
 
 namespace phonlp {
 
-int launch_linear(const float *X, long ldx, const float *W, long ldw, const float *bias, float *Y, long ldy, int M,
+int launch_linear(const char *tag, const float *X, long ldx, const float *W, long ldw, const float *bias, float *Y, long ldy, int M,
                   int N, int K, int relu, const int32_t *sentlens, int L, hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------ arc
@@ -275,10 +275,10 @@ extern "C" int phonlp_deep_biaffine_arc(const float *hidden, int D, int B, int L
     const int M = B * L, KP = kp_of(H), S = n_scorers;
     float *XF = (float *)ws;
     float *T = (float *)((char *)ws + align_up((size_t)M * S * 2 * KP * sizeof(float), 256));
-    int rc = launch_linear(hidden, D, W12, D, b12, XF, (long)S * 2 * KP, M, S * 2 * KP, D, 1, nullptr, 0, st);
+    int rc = launch_linear("linear:arc_w12", hidden, D, W12, D, b12, XF, (long)S * 2 * KP, M, S * 2 * KP, D, 1, nullptr, 0, st);
     if (rc) return rc;
     for (int s = 0; s < S; ++s) {
-        rc = launch_linear(XF + 2 * s * KP, (long)S * 2 * KP, Wbt + (long)s * KP * KP, KP, nullptr, T + s * KP,
+        rc = launch_linear("linear:arc_stage_a", XF + 2 * s * KP, (long)S * 2 * KP, Wbt + (long)s * KP * KP, KP, nullptr, T + s * KP,
                            (long)S * KP, M, KP, KP, 0, nullptr, 0, st);
         if (rc) return rc;
     }
@@ -292,6 +292,7 @@ extern "C" int phonlp_deep_biaffine_arc(const float *hidden, int D, int B, int L
             return fail(PHONLP_ERR_LAUNCH, "deep_biaffine_arc: cannot raise the dynamic LDS limit");
         attr_set = true;
     }
+    ProfScope ps("arc_stage_b", st);
     hipLaunchKernelGGL(arc_kernel, dim3(ceil_div(L, 32), B), dim3(256), lds, st, a);
     return check_launch("arc_kernel");
 }
@@ -312,11 +313,12 @@ extern "C" int phonlp_deep_biaffine_label(const float *hidden, int D, int B, int
     const int M = B * L, KP = kp_of(H);
     float *XF = (float *)ws;
     float *T = (float *)((char *)ws + align_up((size_t)M * 2 * KP * sizeof(float), 256));
-    int rc = launch_linear(hidden, D, W12, D, b12, XF, 2L * KP, M, 2 * KP, D, 1, nullptr, 0, st);
+    int rc = launch_linear("linear:label_w12", hidden, D, W12, D, b12, XF, 2L * KP, M, 2 * KP, D, 1, nullptr, 0, st);
     if (rc) return rc;
-    rc = launch_linear(XF, 2L * KP, Wbt, KP, nullptr, T, (long)O * KP, M, O * KP, KP, 0, nullptr, 0, st);
+    rc = launch_linear("linear:label_stage_a", XF, 2L * KP, Wbt, KP, nullptr, T, (long)O * KP, M, O * KP, KP, 0, nullptr, 0, st);
     if (rc) return rc;
     LabelArgs a{T, XF + KP, label_argmax, scores_opt, (long)O * KP, 2L * KP, B, L, O, KP, ceil_div(L, 128)};
+    ProfScope ps("label_stage_b", st);
     hipLaunchKernelGGL(label_kernel, dim3(B * a.tiles * a.tiles), dim3(512), 0, st, a);
     return check_launch("label_kernel");
 }
@@ -325,6 +327,7 @@ extern "C" int phonlp_gather_labels(const int32_t *label_argmax, const int32_t *
                                     int L, int32_t *rels, void *stream) {
     if (!label_argmax || !heads || !sentlens || !rels || B <= 0 || L <= 0)
         return fail(PHONLP_ERR_SHAPE, "gather_labels: bad argument");
+    ProfScope ps("gather_labels", as_stream(stream));
     hipLaunchKernelGGL(gather_labels_kernel, dim3(ceil_div(B * L, 256)), dim3(256), 0, as_stream(stream), label_argmax,
                        heads, sentlens, B, L, rels);
     return check_launch("gather_labels_kernel");

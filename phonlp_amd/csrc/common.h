@@ -13,6 +13,15 @@ int fail(int code, const char *fmt, ...);
 // Checks the launch that was just enqueued.
 int check_launch(const char *what);
 
+// Optional per-kernel timing (phonlp_profile_begin/_end): records a hipEvent pair on the launch stream
+// around the kernel launched inside the scope.  A no-op unless profiling is enabled.
+struct ProfScope {
+    ProfScope(const char *tag, hipStream_t stream);
+    ~ProfScope();
+    int slot;
+    hipStream_t stream;
+};
+
 constexpr int kWave = 64;
 
 __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

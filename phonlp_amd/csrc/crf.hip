@@ -160,6 +160,7 @@ extern "C" int phonlp_crf_viterbi(const float *logits, const float *trans, const
             return fail(PHONLP_ERR_LAUNCH, "crf_viterbi: cannot raise the dynamic LDS limit");
         attr_set = true;
     }
+    ProfScope ps("viterbi", as_stream(stream));
     hipLaunchKernelGGL(viterbi_kernel, dim3(ceil_div(B, wpb)), dim3(wpb * 64), lds, as_stream(stream), logits, trans,
                        sentlens, B, L, T, wave_floats, tags, best);
     return check_launch("viterbi_kernel");
@@ -183,6 +184,7 @@ extern "C" int phonlp_crf_log_partition(const float *logits, const float *trans,
             return fail(PHONLP_ERR_LAUNCH, "crf_log_partition: cannot raise the dynamic LDS limit");
         attr_set = true;
     }
+    ProfScope ps("crf_forward", as_stream(stream));
     hipLaunchKernelGGL(crf_forward_kernel, dim3(ceil_div(B, wpb)), dim3(wpb * 64), lds, as_stream(stream), logits,
                        trans, pad_mask, sentlens, gold_tags, B, L, T, wave_floats, log_norm, unary, binary);
     return check_launch("crf_forward_kernel");

@@ -1,6 +1,11 @@
 // POS head tail (softmax / arg-max / soft POS embedding), NER emissions, dep_hid, and the error plumbing.
 #include <stdarg.h>
 #include <stdio.h>
+#include <string.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
 
 #include "common.h"
 
@@ -22,7 +27,35 @@ int check_launch(const char *what) {
     return PHONLP_OK;
 }
 
-int launch_linear(const float *X, long ldx, const float *W, long ldw, const float *bias, float *Y, long ldy, int M,
+// ---------------------------------------------------------------------------------- profiling
+namespace {
+struct ProfState {
+    std::mutex mu;
+    bool on = false;
+    int cap = 0, used = 0;
+    std::vector<hipEvent_t> ev;      // 2 per sample
+    std::vector<int> tag;            // tag id per sample
+    std::vector<std::string> names;  // tag registry
+} g_prof;
+}  // namespace
+
+ProfScope::ProfScope(const char *tag, hipStream_t s) : slot(-1), stream(s) {
+    if (!g_prof.on) return;
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    if (!g_prof.on || g_prof.used >= g_prof.cap) return;
+    int id = -1;
+    for (size_t i = 0; i < g_prof.names.size(); ++i)
+        if (g_prof.names[i] == tag) { id = (int)i; break; }
+    if (id < 0) { id = (int)g_prof.names.size(); g_prof.names.emplace_back(tag); }
+    slot = g_prof.used++;
+    g_prof.tag[slot] = id;
+    (void)hipEventRecord(g_prof.ev[2 * slot], stream);
+}
+ProfScope::~ProfScope() {
+    if (slot >= 0) (void)hipEventRecord(g_prof.ev[2 * slot + 1], stream);
+}
+
+int launch_linear(const char *tag, const float *X, long ldx, const float *W, long ldw, const float *bias, float *Y, long ldy, int M,
                   int N, int K, int relu, const int32_t *sentlens, int L, hipStream_t stream);
 
 // One wavefront per token.  logits [M, U] (U <= 64) -> pos_pred, feat = [enc | softmax(logits) . emb].
@@ -68,7 +101,44 @@ __global__ __launch_bounds__(256) void pos_tail_kernel(const float *enc, long ld
 
 using namespace phonlp;
 
-extern "C" int phonlp_version(void) { return 100; }
+extern "C" int phonlp_version(void) { return 101; }
+
+extern "C" int phonlp_profile_begin(int max_samples) {
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    if (max_samples <= 0) return fail(PHONLP_ERR_SHAPE, "profile_begin: max_samples <= 0");
+    while ((int)g_prof.ev.size() < 2 * max_samples) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return fail(PHONLP_ERR_LAUNCH, "profile_begin: hipEventCreate failed");
+        g_prof.ev.push_back(e);
+    }
+    g_prof.tag.assign(max_samples, -1);
+    g_prof.cap = max_samples;
+    g_prof.used = 0;
+    g_prof.on = true;
+    return PHONLP_OK;
+}
+
+extern "C" int phonlp_profile_end(float *ms_out_host, int32_t *tag_out_host, int cap) {
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    g_prof.on = false;
+    int n = g_prof.used < cap ? g_prof.used : cap;
+    for (int i = 0; i < n; ++i) {
+        float ms = 0.f;
+        if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess ||
+            hipEventElapsedTime(&ms, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess)
+            return fail(PHONLP_ERR_LAUNCH, "profile_end: event query failed");
+        ms_out_host[i] = ms;
+        tag_out_host[i] = g_prof.tag[i];
+    }
+    g_prof.used = 0;
+    return n;
+}
+
+extern "C" const char *phonlp_profile_tag_name(int id) {
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    if (id < 0 || id >= (int)g_prof.names.size()) return "";
+    return g_prof.names[id].c_str();
+}
 extern "C" const char *phonlp_last_error(void) { return g_err; }
 
 extern "C" size_t phonlp_pos_head_ws_bytes(int B, int L, int E, int H, int U, int TE) {
@@ -92,10 +162,11 @@ extern "C" int phonlp_pos_head(const float *enc, int ld_enc, const int32_t *sent
     const int M = B * L;
     float *hid = (float *)ws;
     float *logits = upos_logits ? upos_logits : (float *)((char *)ws + align_up((size_t)M * H * sizeof(float), 256));
-    int rc = launch_linear(enc, ld_enc, Whid, E, bhid, hid, H, M, H, E, 1, sentlens, L, st);
+    int rc = launch_linear("linear:upos_hid", enc, ld_enc, Whid, E, bhid, hid, H, M, H, E, 1, sentlens, L, st);
     if (rc) return rc;
-    rc = launch_linear(hid, H, Wclf, H, bclf, logits, U, M, U, H, 0, sentlens, L, st);
+    rc = launch_linear("linear:upos_clf", hid, H, Wclf, H, bclf, logits, U, M, U, H, 0, sentlens, L, st);
     if (rc) return rc;
+    ProfScope ps("pos_tail", st);
     hipLaunchKernelGGL(pos_tail_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, st, enc, (long)ld_enc, logits, emb, sentlens,
                        M, L, E, U, TE, feat, pos_pred);
     return check_launch("pos_tail_kernel");
@@ -105,12 +176,12 @@ extern "C" int phonlp_ner_emission(const float *feat, int D, const int32_t *sent
                                    const float *bner, int T, float *logits, void *stream) {
     if (!feat || !sentlens || !Wner || !logits || B <= 0 || L <= 0 || T <= 0)
         return fail(PHONLP_ERR_SHAPE, "ner_emission: bad argument");
-    return launch_linear(feat, D, Wner, D, bner, logits, T, B * L, T, D, 1, sentlens, L, as_stream(stream));
+    return launch_linear("linear:ner_emission", feat, D, Wner, D, bner, logits, T, B * L, T, D, 1, sentlens, L, as_stream(stream));
 }
 
 extern "C" int phonlp_dep_hidden(const float *feat, int D, const int32_t *sentlens, int B, int L, const float *Wdep,
                                  const float *bdep, float *hidden, void *stream) {
     if (!feat || !sentlens || !Wdep || !hidden || B <= 0 || L <= 0)
         return fail(PHONLP_ERR_SHAPE, "dep_hidden: bad argument");
-    return launch_linear(feat, D, Wdep, D, bdep, hidden, D, B * L, D, D, 0, sentlens, L, as_stream(stream));
+    return launch_linear("linear:dep_hid", feat, D, Wdep, D, bdep, hidden, D, B * L, D, D, 0, sentlens, L, as_stream(stream));
 }

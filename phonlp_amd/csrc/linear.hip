@@ -83,13 +83,14 @@ __global__ __launch_bounds__(WM *WN * 64) void linear_kernel(LinearArgs a) {
     }
 }
 
-int launch_linear(const float *X, long ldx, const float *W, long ldw, const float *bias, float *Y, long ldy, int M,
+int launch_linear(const char *tag, const float *X, long ldx, const float *W, long ldw, const float *bias, float *Y, long ldy, int M,
                   int N, int K, int relu, const int32_t *sentlens, int L, hipStream_t stream) {
     if (!X || !W || !Y || M <= 0 || N <= 0 || K <= 0) return fail(PHONLP_ERR_SHAPE, "linear: bad argument");
     if ((K & 3) || (ldx & 3) || (ldw & 3) || ((uintptr_t)X & 15) || ((uintptr_t)W & 15))
         return fail(PHONLP_ERR_SHAPE, "linear: K, ldx, ldw must be multiples of 4 and X, W 16-byte aligned");
     if (sentlens && L <= 0) return fail(PHONLP_ERR_SHAPE, "linear: sentlens given but L <= 0");
     LinearArgs a{X, W, bias, Y, sentlens, ldx, ldw, ldy, M, N, K, L, relu, 0, 0};
+    ProfScope ps(tag, stream);
     if (N <= 64) {
         a.num_m = ceil_div(M, 128);
         a.num_n = ceil_div(N, 32);
@@ -137,7 +138,7 @@ using namespace phonlp;
 
 extern "C" int phonlp_linear(const float *X, int ldx, const float *W, int ldw, const float *bias, float *Y, int ldy,
                              int M, int N, int K, int relu, const int32_t *sentlens, int L, void *stream) {
-    return launch_linear(X, ldx, W, ldw, bias, Y, ldy, M, N, K, relu, sentlens, L, as_stream(stream));
+    return launch_linear("linear", X, ldx, W, ldw, bias, Y, ldy, M, N, K, relu, sentlens, L, as_stream(stream));
 }
 
 extern "C" int phonlp_pack_scorer_linear(const float *W1, const float *b1, const float *W2, const float *b2, int H,

@@ -385,6 +385,7 @@ extern "C" int phonlp_mst_one_root(const float *arc, const int32_t *sentlens, in
             return fail(PHONLP_ERR_LAUNCH, "mst_one_root: cannot raise the dynamic LDS limit");
         attr_set = true;
     }
+    ProfScope ps("mst", as_stream(stream));
     if (in_lds) {
         lds += (size_t)L * a.pitch * sizeof(double);
         hipLaunchKernelGGL(mst_kernel<true>, dim3(B), dim3(threads), lds, as_stream(stream), a);
