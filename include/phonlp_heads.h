@@ -39,7 +39,7 @@ extern "C" {
 #define PHONLP_MST_NO_FINITE_TREE 1 /* ref chuliu_edmonds.py:162-168: the reference asserts here */
 
 /* Padded feature width used by the biaffine kernels for a hidden size H: H real features, one
- * ones-column (ref biaffine.py:63-64), zero padding up to a multiple of 32. */
+ * ones-column (ref biaffine.py:63-64), zero padding up to a multiple of 8. */
 int phonlp_kp(int H);
 
 int phonlp_version(void);

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void arc_kernel(ArcArgs a) {
     const int b = blockIdx.y, i0 = blockIdx.x * 32;
     const int L = a.L, KP = a.KP, LP = a.LP;
     const int iv = L - i0;
-    const int nk = KP / BK;
+    const int nk = (KP + BK - 1) / BK;
     const int total = a.S * nk;
     const float *Tb = a.T + ((long)b * L + i0) * a.ldT;
     const long plane = (long)a.B * L * L;
@@ -80,9 +80,10 @@ __global__ __launch_bounds__(256) void arc_kernel(ArcArgs a) {
                 slab_load(rb, Xb + (2 * s2 + 1) * KP, a.ldx, jv, k2, KP, tid);
             }
             const float *Bw = Bs + wave * 32 * PITCH;
-            if (s == 0) mma_slab<1, 1>(As, Bw, lane, acc0);
-            else if (s == 1) mma_slab<1, 1>(As, Bw, lane, acc1);
-            else mma_slab<1, 1>(As, Bw, lane, acc2);
+            const int depth = slab_depth((it - s * nk) * BK, KP);
+            if (s == 0) mma_slab<1, 1>(As, Bw, lane, acc0, depth);
+            else if (s == 1) mma_slab<1, 1>(As, Bw, lane, acc1, depth);
+            else mma_slab<1, 1>(As, Bw, lane, acc2, depth);
             __syncthreads();
             if (it + 1 < total) {
                 slab_store(ra, As, tid);
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(512) void label_kernel(LabelArgs a) {
     const int iv = L - i0, jv = L - j0;
     const float *Tb = a.T + ((long)b * L + i0) * a.ldT;
     const float *Xb = a.X2 + ((long)b * L + j0) * a.ldx;
-    const int nk = KP / BK;
+    const int nk = (KP + BK - 1) / BK;
     const int total = O * nk;
 
     f32x16 acc[2][1];
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(512) void label_kernel(LabelArgs a) {
             slab_load(ra, Tb + (long)o2 * KP, a.ldT, iv, k2 * BK, KP, tid);
             slab_load(rb, Xb, a.ldx, jv, k2 * BK, KP, tid);
         }
-        mma_slab<2, 1>(As + wm * 64 * PITCH, Bs + wn * 32 * PITCH, lane, acc);
+        mma_slab<2, 1>(As + wm * 64 * PITCH, Bs + wn * 32 * PITCH, lane, acc, slab_depth(kk * BK, KP));
         if (kk == nk - 1) {
             const int col = j0 + wn * 32 + (lane & 31);
 #pragma unroll

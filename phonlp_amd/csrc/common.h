@@ -29,7 +29,7 @@ __host__ __device__ inline size_t align_up(size_t v, size_t a) { return (v + a -
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
-// KP: hidden features + ones column, zero-padded to the MFMA slab depth (32).
-__host__ __device__ inline int kp_of(int H) { return (H + 1 + 31) / 32 * 32; }
+// KP: hidden features + ones column, zero-padded to the MFMA k-group (8 floats = two 16-byte LDS reads).
+__host__ __device__ inline int kp_of(int H) { return (H + 1 + 7) / 8 * 8; }
 
 }  // namespace phonlp

@@ -1,5 +1,8 @@
 // Dense layer  Y = act(X . W^T + bias)  on the fp32 MFMA tile engine, plus the one-time weight
 // packing kernels.  See include/phonlp_heads.h for the reference call sites each entry replaces.
+#include <stdlib.h>
+#include <string.h>
+
 #include "mma_f32.h"
 
 namespace phonlp {
@@ -16,13 +19,21 @@ struct LinearArgs {
     int num_m, num_n;
 };
 
-// BM x BN block tile, WM x WN waves, each wave a (BM/WM) x (BN/WN) sub-tile.
-template <int BM, int BN, int WM, int WN>
+// BM x BN block tile, WM x WN waves, each wave a (BM/WM) x (BN/WN) sub-tile.  TAG only names the
+// instantiation (TAG 1 = bilinear stage A of the label scorer, so profilers list it on its own row).
+//
+// K loop: two LDS slab buffers, ONE barrier per slab.  Iteration k issues the global loads of slab k+1,
+// multiplies slab k out of buffer k&1, then writes slab k+1 into buffer (k+1)&1; the barrier that ends the
+// iteration orders those writes before the next iteration's reads and this iteration's reads before the
+// writes of iteration k+1 into the same buffer.
+// Epilogue: bias and row-liveness are fetched up front in one batch, so the stores issue back to back
+// (a load between stores would make every s_waitcnt vmcnt(0) wait for the stores as well).
+template <int BM, int BN, int WM, int WN, int TAG>
 __global__ __launch_bounds__(WM *WN * 64) void linear_kernel(LinearArgs a) {
     constexpr int THREADS = WM * WN * 64;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * PITCH];
-    float *As = lds, *Bs = lds + BM * PITCH;
+    constexpr int BUF = (BM + BN) * PITCH;
+    __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -45,41 +56,86 @@ __global__ __launch_bounds__(WM *WN * 64) void linear_kernel(LinearArgs a) {
     Slab<BN, THREADS> rb;
     slab_load(ra, Xt, a.ldx, mv, 0, a.K, tid);
     slab_load(rb, Wt, a.ldw, nv, 0, a.K, tid);
-    slab_store(ra, As, tid);
-    slab_store(rb, Bs, tid);
+    slab_store(ra, lds, tid);
+    slab_store(rb, lds + BM * PITCH, tid);
     __syncthreads();
+    int cur = 0;
     for (int k0 = 0; k0 < a.K; k0 += BK) {
         const bool more = k0 + BK < a.K;
         if (more) {
             slab_load(ra, Xt, a.ldx, mv, k0 + BK, a.K, tid);
             slab_load(rb, Wt, a.ldw, nv, k0 + BK, a.K, tid);
         }
-        mma_slab<TM, TN>(As + wm * TM * 32 * PITCH, Bs + wn * TN * 32 * PITCH, lane, acc);
-        __syncthreads();
+        const float *As = lds + cur * BUF, *Bs = As + BM * PITCH;
+        mma_slab<TM, TN>(As + wm * TM * 32 * PITCH, Bs + wn * TN * 32 * PITCH, lane, acc, slab_depth(k0, a.K));
         if (more) {
-            slab_store(ra, As, tid);
-            slab_store(rb, Bs, tid);
-            __syncthreads();
+            float *An = lds + (cur ^ 1) * BUF;
+            slab_store(ra, An, tid);
+            slab_store(rb, An + BM * PITCH, tid);
         }
+        __syncthreads();
+        cur ^= 1;
     }
 
+    // ---- epilogue: each wave transposes its accumulators through its own LDS patch so that every global
+    // store is a 16-byte-per-lane row segment (a 32x32 accumulator register is one dword per lane: 4x the
+    // store instructions and quarter-line writes if stored directly).
+    constexpr int WCOLS = TN * 32, EP = WCOLS + 4;
+    static_assert(WM * WN * 32 * EP <= 2 * BUF, "epilogue patch must fit the slab buffers");
+    float *ep = lds + wave * 32 * EP;
+    constexpr int LPR = WCOLS / 4;   // lanes per row
+    constexpr int RPI = 64 / LPR;    // rows per wave-instruction
+    const int c4 = (lane % LPR) * 4;
+    const int col = n0 + wn * WCOLS + c4;
+    const int rsub = lane / LPR;
+    const bool vec_ok = ((a.ldy & 3) == 0) && (((uintptr_t)a.Y & 15) == 0) && (col + 3 < a.N);
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.bias) {
+        if (col < a.N) bv.x = a.bias[col];
+        if (col + 1 < a.N) bv.y = a.bias[col + 1];
+        if (col + 2 < a.N) bv.z = a.bias[col + 2];
+        if (col + 3 < a.N) bv.w = a.bias[col + 3];
+    }
+    unsigned live[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        live[i] = 0xFFFFFFFFu;
+        if (a.sentlens) {
+            live[i] = 0;
+#pragma unroll
+            for (int it = 0; it < 32 / RPI; ++it) {
+                const int row = m0 + (wm * TM + i) * 32 + it * RPI + rsub;
+                if (row < a.M && (row % a.L) < a.sentlens[row / a.L]) live[i] |= 1u << it;
+            }
+        }
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = m0 + (wm * TM + i) * 32 + acc_row(r, lane);
-            if (row >= a.M) continue;
-            bool live = true;
-            if (a.sentlens) live = (row % a.L) < a.sentlens[row / a.L];
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
-                if (col >= a.N) continue;
-                float v = acc[i][j][r] + (a.bias ? a.bias[col] : 0.f);
-                if (a.relu) v = fmaxf(v, 0.f);
-                a.Y[(long)row * a.ldy + col] = live ? v : 0.f;
+            for (int r = 0; r < 16; ++r) ep[acc_row(r, lane) * EP + j * 32 + (lane & 31)] = acc[i][j][r];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+        for (int it = 0; it < 32 / RPI; ++it) {
+            const int lrow = it * RPI + rsub;
+            const int row = m0 + (wm * TM + i) * 32 + lrow;
+            float4 v = *reinterpret_cast<const float4 *>(ep + lrow * EP + c4);
+            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+            if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (!((live[i] >> it) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row >= a.M || col >= a.N) continue;
+            float *y = a.Y + (long)row * a.ldy + col;
+            if (vec_ok) {
+                *reinterpret_cast<float4 *>(y) = v;
+            } else {
+                y[0] = v.x;
+                if (col + 1 < a.N) y[1] = v.y;
+                if (col + 2 < a.N) y[2] = v.z;
+                if (col + 3 < a.N) y[3] = v.w;
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
 }
 
@@ -90,15 +146,31 @@ int launch_linear(const char *tag, const float *X, long ldx, const float *W, lon
         return fail(PHONLP_ERR_SHAPE, "linear: K, ldx, ldw must be multiples of 4 and X, W 16-byte aligned");
     if (sentlens && L <= 0) return fail(PHONLP_ERR_SHAPE, "linear: sentlens given but L <= 0");
     LinearArgs a{X, W, bias, Y, sentlens, ldx, ldw, ldy, M, N, K, L, relu, 0, 0};
+    const bool stage_a = tag && !strcmp(tag, "linear:label_stage_a");
     ProfScope ps(tag, stream);
     if (N <= 64) {
         a.num_m = ceil_div(M, 128);
         a.num_n = ceil_div(N, 32);
-        hipLaunchKernelGGL((linear_kernel<128, 32, 4, 1>), dim3(a.num_m * a.num_n), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL((linear_kernel<128, 32, 4, 1, 0>), dim3(a.num_m * a.num_n), dim3(256), 0, stream, a);
+    } else if (getenv("PHONLP_GEMM_CFG") && atoi(getenv("PHONLP_GEMM_CFG")) == 1) {
+        a.num_m = ceil_div(M, 128);
+        a.num_n = ceil_div(N, 128);
+        hipLaunchKernelGGL((linear_kernel<128, 128, 2, 4, 2>), dim3(a.num_m * a.num_n), dim3(512), 0, stream, a);
+    } else if (getenv("PHONLP_GEMM_CFG") && atoi(getenv("PHONLP_GEMM_CFG")) == 2) {
+        a.num_m = ceil_div(M, 256);
+        a.num_n = ceil_div(N, 128);
+        hipLaunchKernelGGL((linear_kernel<256, 128, 4, 2, 2>), dim3(a.num_m * a.num_n), dim3(512), 0, stream, a);
+    } else if (getenv("PHONLP_GEMM_CFG") && atoi(getenv("PHONLP_GEMM_CFG")) == 3) {
+        a.num_m = ceil_div(M, 128);
+        a.num_n = ceil_div(N, 64);
+        hipLaunchKernelGGL((linear_kernel<128, 64, 4, 1, 2>), dim3(a.num_m * a.num_n), dim3(256), 0, stream, a);
     } else {
         a.num_m = ceil_div(M, 128);
         a.num_n = ceil_div(N, 128);
-        hipLaunchKernelGGL((linear_kernel<128, 128, 2, 2>), dim3(a.num_m * a.num_n), dim3(256), 0, stream, a);
+        if (stage_a)
+            hipLaunchKernelGGL((linear_kernel<128, 128, 2, 2, 1>), dim3(a.num_m * a.num_n), dim3(256), 0, stream, a);
+        else
+            hipLaunchKernelGGL((linear_kernel<128, 128, 2, 2, 0>), dim3(a.num_m * a.num_n), dim3(256), 0, stream, a);
     }
     return check_launch("linear_kernel");
 }

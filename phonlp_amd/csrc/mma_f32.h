@@ -56,15 +56,15 @@ __device__ __forceinline__ void slab_store(const Slab<ROWS, THREADS> &s, float *
     }
 }
 
-// One BK-deep slab of MFMAs for this wave's sub-tile.  As/Bs point at the wave's first row of
-// the A / B slab images.  acc[i][j] register r, lane l holds
+// One slab of MFMAs for this wave's sub-tile.  As/Bs point at the wave's first row of the A / B slab
+// images.  acc[i][j] register r, lane l holds
 //   C[row = i*32 + (r&3) + 8*(r>>2) + 4*(l>>5)][col = j*32 + (l&31)].
-template <int TM, int TN>
-__device__ __forceinline__ void mma_slab(const float *As, const float *Bs, int lane, f32x16 (&acc)[TM][TN]) {
+template <int TM, int TN, int DEPTH>
+__device__ __forceinline__ void mma_slab_d(const float *As, const float *Bs, int lane, f32x16 (&acc)[TM][TN]) {
     const int r = lane & 31;
     const int h = lane >> 5;
 #pragma unroll
-    for (int kb = 0; kb < BK; kb += 8) {
+    for (int kb = 0; kb < DEPTH; kb += 8) {
         f32x4 a[TM], b[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4 *>(As + (i * 32 + r) * PITCH + kb + 4 * h);
@@ -78,6 +78,23 @@ __device__ __forceinline__ void mma_slab(const float *As, const float *Bs, int l
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
     }
+}
+
+// `depth` = number of valid k columns in this slab rounded up to 8 (wave-uniform).  The last slab of a K
+// that is not a multiple of 32 (868, 408) skips the k-groups that hold only zero fill.
+template <int TM, int TN>
+__device__ __forceinline__ void mma_slab(const float *As, const float *Bs, int lane, f32x16 (&acc)[TM][TN],
+                                         int depth = BK) {
+    if (depth >= 32) mma_slab_d<TM, TN, 32>(As, Bs, lane, acc);
+    else if (depth > 16) mma_slab_d<TM, TN, 24>(As, Bs, lane, acc);
+    else if (depth > 8) mma_slab_d<TM, TN, 16>(As, Bs, lane, acc);
+    else mma_slab_d<TM, TN, 8>(As, Bs, lane, acc);
+}
+
+// valid depth (multiple of 8) of the slab starting at k0
+__device__ __forceinline__ int slab_depth(int k0, int K) {
+    const int d = K - k0;
+    return d >= BK ? BK : ((d + 7) & ~7);
 }
 
 __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }

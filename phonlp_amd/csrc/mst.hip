@@ -22,6 +22,7 @@
 // summation order for cycle_scores.sum() (:75) and tree_probs.sum() (:158), strict '>' for
 // first-maximum ties.
 #include <limits.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -37,9 +38,32 @@ struct MstArgs {
     long stack_stride;  // u16 per sentence
     long gmat_stride;   // doubles per sentence
     int B, L, pitch, lvl_stride;
+    long long *dbg;  // diagnostic builds only (-DMST_STAMPS): 16 counters per sentence
 };
 
+#ifdef MST_STAMPS
+#define STAMP(k)                                              \
+    do {                                                      \
+        if (tid == 0) {                                       \
+            const long long now_ = clock64();                 \
+            stamp_acc[k] += now_ - stamp_t;                   \
+            stamp_t = now_;                                   \
+        }                                                     \
+    } while (0)
+#else
+#define STAMP(k) do {} while (0)
+#endif
+
 #define NEG_INF_D (-__builtin_inf())
+
+// Workgroup barrier that orders LDS traffic only: the per-level expansion records are stored to global
+// memory and not read again before the (full) barrier that precedes the expansion, so the contraction
+// loop need not wait for those stores to be acknowledged at every barrier.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 
 // numpy's float64 pairwise add-reduction order (verified against numpy 2.2, n = 1..1000).
 __device__ inline double np_sum_block(const double *a, int n) {
@@ -69,7 +93,7 @@ template <>
 __device__ inline double np_sum<0>(const double *a, int n) { return np_sum_block(a, n); }
 
 // scalars kept in LDS
-enum { SC_M = 0, SC_NEXT, SC_NROOT, SC_FINITE, SC_C, SC_TAKE, SC_COUNT = 16 };
+enum { SC_M = 0, SC_NEXT, SC_NROOT, SC_FINITE, SC_NNEED, SC_TAKE, SC_COUNT = 16 };
 
 template <bool IN_LDS>
 __global__ __launch_bounds__(1024) void mst_kernel(MstArgs a) {
@@ -108,7 +132,16 @@ __global__ __launch_bounds__(1024) void mst_kernel(MstArgs a) {
     const float *arc = a.arc + (long)b * L * L;
     uint16_t *stack = a.stack + (long)b * a.stack_stride;
 #define SM(r, c) S[(long)(r) * pitch + (c)]
+#define LSYNC()                     \
+    do {                            \
+        if (IN_LDS) lds_barrier();  \
+        else __syncthreads();       \
+    } while (0)
 
+#ifdef MST_STAMPS
+    long long stamp_acc[16] = {0};
+    long long stamp_t = clock64();
+#endif
     int root = -1;  // -1: unconstrained first run (ref :137); >= 1: set_root(root) (ref :143-149)
     double best_score = NEG_INF_D;
     int have_best = 0;
@@ -127,15 +160,18 @@ __global__ __launch_bounds__(1024) void mst_kernel(MstArgs a) {
             if (i == 0) v = j == 0 ? 0.0 : NEG_INF_D;       // ref :56-57
             SM(i, j) = v;
         }
-        if (tid < l) { node[tid] = tid; need[tid] = 1; }
+        if (tid < l) { node[tid] = tid; need[tid] = tid; }  // need[]: list of rows whose arg-max must be (re)scanned
+        if (tid == 0) sc[SC_NNEED] = l;
         int n = l, levels = 0;
         __syncthreads();
+        STAMP(0);
 
         // -------------------------------------------------------------- contraction loop
         for (;;) {
             // (1) first-maximum arg-max of every row that needs it, in logical column order
-            for (int row = wave; row < n; row += nwaves) {
-                if (!need[row]) continue;
+            const int nneed = sc[SC_NNEED];
+            for (int q = wave; q < nneed; q += nwaves) {
+                const int row = need[q];
                 const int rs = node[row];
                 double bv = NEG_INF_D;
                 int bi = INT_MAX;
@@ -152,12 +188,13 @@ __global__ __launch_bounds__(1024) void mst_kernel(MstArgs a) {
                 }
                 if (lane == 0) hdA[row] = bi;
             }
-            __syncthreads();
+            LSYNC();
+            STAMP(1);
             // (2) cycles by pointer doubling: after R rounds (2^R >= n) P[v] lies on v's cycle and
             //     mn[v] is the minimum over >= n consecutive nodes, i.e. the whole cycle for cycle nodes
             if (tid < n) { P0[tid] = hdA[tid]; mn0[tid] = tid; flag[tid] = 0; }
-            if (tid == 0) sc[SC_M] = 0;
-            __syncthreads();
+            if (tid == 0) { sc[SC_M] = 0; sc[SC_NNEED] = 0; }
+            LSYNC();
             int *Pc = P0, *Pn = P1, *mc = mn0, *mx = mn1;
             for (int span = 1; span < n; span <<= 1) {
                 if (tid < n) {
@@ -166,15 +203,16 @@ __global__ __launch_bounds__(1024) void mst_kernel(MstArgs a) {
                     const int m1 = mc[tid], m2 = mc[p];
                     mx[tid] = m1 < m2 ? m1 : m2;
                 }
-                __syncthreads();
+                LSYNC();
                 int *t1 = Pc; Pc = Pn; Pn = t1;
                 int *t2 = mc; mc = mx; mx = t2;
             }
             if (tid < n) flag[Pc[tid]] = 1;
-            __syncthreads();
+            LSYNC();
             if (tid < n && flag[tid]) atomicMax(&sc[SC_M], mc[tid]);
-            __syncthreads();
+            LSYNC();
             const int M = sc[SC_M];
+            STAMP(2);
             if (M == 0) break;  // only ROOT's self loop is left: hdA is a tree
             if (levels >= l) { err = 1; break; }
             // (3) the chosen cycle, member / non-member lists in ascending logical order
@@ -182,7 +220,7 @@ __global__ __launch_bounds__(1024) void mst_kernel(MstArgs a) {
             if (tid < n) { f = (flag[tid] && mc[tid] == M) ? 1 : 0; incyc[tid] = f; }
             const unsigned long long bal = __ballot(f);
             if (lane == 0) wtot[wave] = __popcll(bal);
-            __syncthreads();
+            LSYNC();
             int rc = __popcll(bal & ((1ull << lane) - 1ull));
             int c = 0;
             for (int w = 0; w < nwaves; ++w) {
@@ -196,16 +234,18 @@ __global__ __launch_bounds__(1024) void mst_kernel(MstArgs a) {
                 else rest[tid - rc] = tid;
                 rankr[tid] = tid - rc;
             }
-            __syncthreads();
+            LSYNC();
+            STAMP(3);
             // (4) cycle edge scores and their numpy-ordered sum (ref :73-75)
             if (tid < c) {
                 const int v = cyc[tid];
                 edge[tid] = SM(node[v], node[hdA[v]]);
             }
-            __syncthreads();
+            LSYNC();
             if (tid == 0) dsc[0] = np_sum<4>(edge, c);
-            __syncthreads();
+            LSYNC();
             const double total = dsc[0];
+            STAMP(4);
             // (5) best way into the cycle from every outside node (ref :84,:88,:97) and best head
             //     inside the cycle for every outside node (ref :86,:90,:99)
             int my_slot = 0, my_newhead = 0, my_need = 0;
@@ -244,25 +284,31 @@ __global__ __launch_bounds__(1024) void mst_kernel(MstArgs a) {
                     rec[2 + n + c + 2 * k + tid] = (uint16_t)lpick[tid];
                 }
             }
-            __syncthreads();
+            LSYNC();
+            STAMP(5);
             // (7) contract in place: metanode row/column into slot `ms`, new logical order
             if (tid < k) {
                 SM(ms, my_slot) = my_ev;
                 SM(my_slot, ms) = my_lv;
                 node[tid] = my_slot;
                 hdA[tid] = my_newhead;
-                need[tid] = my_need;
+                if (my_need) need[atomicAdd(&sc[SC_NNEED], 1)] = tid;
             }
             if (tid == 0) {
                 SM(ms, ms) = NEG_INF_D;
                 node[k] = ms;
-                need[k] = 1;
+                need[atomicAdd(&sc[SC_NNEED], 1)] = k;
             }
             n = k + 1;
             ++levels;
-            __syncthreads();
+            LSYNC();
+            STAMP(6);
+#ifdef MST_STAMPS
+            if (tid == 0) stamp_acc[10] += 1;
+#endif
         }
         if (err) break;
+        __syncthreads();  // full barrier: the level records (global stores) must be visible to the expansion
         // -------------------------------------------------------------- expansion (ref :105-128)
         int *cur = hdA, *oth = hdB;
         for (int lev = levels - 1; lev >= 0; --lev) {
@@ -282,6 +328,10 @@ __global__ __launch_bounds__(1024) void mst_kernel(MstArgs a) {
             __syncthreads();
             int *t = cur; cur = oth; oth = t;
         }
+        STAMP(7);
+#ifdef MST_STAMPS
+        if (tid == 0) stamp_acc[11] += 1;
+#endif
         // `cur` now holds the tree over the original l nodes
         // -------------------------------------------------------------- single-root logic (ref :137-169)
         if (root < 0) {
@@ -293,6 +343,10 @@ __global__ __launch_bounds__(1024) void mst_kernel(MstArgs a) {
             }
             __syncthreads();
             if (sc[SC_NROOT] == 1) {
+#ifdef MST_STAMPS
+                if (tid == 0 && a.dbg)
+                    for (int k = 0; k < 16; ++k) a.dbg[(long)b * 16 + k] = stamp_acc[k];
+#endif
                 if (tid < l) hout[tid] = cur[tid];
                 if (tid == 0) a.status[b] = PHONLP_MST_OK;
                 return;
@@ -330,9 +384,14 @@ __global__ __launch_bounds__(1024) void mst_kernel(MstArgs a) {
         }
         const int next = sc[SC_NEXT];
         __syncthreads();
+        STAMP(8);
         if (next == INT_MAX) break;
         root = next;
     }
+#ifdef MST_STAMPS
+    if (tid == 0 && a.dbg)
+        for (int k = 0; k < 16; ++k) a.dbg[(long)b * 16 + k] = stamp_acc[k];
+#endif
     if (err) {
         if (tid == 0) a.status[b] = 2;
         return;
@@ -344,6 +403,7 @@ __global__ __launch_bounds__(1024) void mst_kernel(MstArgs a) {
         a.status[b] = PHONLP_MST_NO_FINITE_TREE;
     }
 #undef SM
+#undef LSYNC
 }
 
 static size_t mst_aux_bytes(int L) { return (size_t)L * 8 * 3 + 32 + (size_t)L * 4 * 17 + (SC_COUNT + 16) * 4; }
@@ -373,6 +433,9 @@ extern "C" int phonlp_mst_one_root(const float *arc, const int32_t *sentlens, in
     a.lvl_stride = mst_lvl_stride(L);
     a.stack_stride = (long)L * a.lvl_stride;
     a.B = B; a.L = L; a.pitch = mst_pitch(L);
+#ifdef MST_STAMPS
+    a.dbg = (long long *)getenv("PHONLP_MST_DBG") ? (long long *)strtoull(getenv("PHONLP_MST_DBG"), nullptr, 0) : nullptr;
+#endif
     const bool in_lds = mst_fits_lds(L);
     const int threads = L <= 256 ? 256 : (L + 63) / 64 * 64;
     size_t lds = mst_aux_bytes(L);

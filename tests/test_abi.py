@@ -34,8 +34,8 @@ def test_header_symbols_exported(heads_lib):
 
 
 def test_kp_and_version(heads_lib):
-    assert heads_lib.phonlp_kp(400) == 416  # 400 features + ones column, padded to 32
-    assert heads_lib.phonlp_kp(16) == 32
+    assert heads_lib.phonlp_kp(400) == 408  # 400 features + ones column, padded to 8
+    assert heads_lib.phonlp_kp(16) == 24
     assert heads_lib.phonlp_version() >= 100
 
 
@@ -48,7 +48,7 @@ def test_argument_errors_without_gpu(heads_lib):
     assert heads_lib.phonlp_crf_viterbi(one, one, one, 1, 4, 65, one, None, None) == -4  # T > 64 unsupported
     assert heads_lib.phonlp_linear(one, 6, one, 6, None, one, 4, 2, 2, 6, 0, None, 0, None) == -1  # K % 4 != 0
     assert heads_lib.phonlp_mst_ws_bytes(256, 128) > 0
-    assert heads_lib.phonlp_biaffine_label_ws_bytes(256, 128, 400, 33) == 256 * 128 * (2 * 416 + 33 * 416) * 4
+    assert heads_lib.phonlp_biaffine_label_ws_bytes(256, 128, 400, 33) == 256 * 128 * (2 * 408 + 33 * 408) * 4
 
 
 def test_missing_library_fails_loudly(monkeypatch):

@@ -1,0 +1,26 @@
+"""Diagnostic: per-phase cycle shares of the MST kernel (needs tools/libphonlp_heads_stamps.so, built with -DMST_STAMPS)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from phonlp_amd import _lib
+_lib.LIB_PATH = os.path.join(ROOT, "tools", "libphonlp_heads_stamps.so")
+from phonlp_amd import HeadWeights, TaskHeads, ops, synthetic as S
+dev = torch.device("cuda:0")
+B, L = 256, 128
+heads = TaskHeads(HeadWeights.from_state_dict(S.make_state_dict(), dev))
+enc_dep, _ = S.make_encoder_outputs(B, L)
+lens = torch.tensor([L] * B, dtype=torch.int32, device=dev)
+arc = heads.parser(enc_dep.to(dev), lens)["arc_logp"]
+dbg = torch.zeros(B, 16, dtype=torch.int64, device=dev)
+os.environ["PHONLP_MST_DBG"] = str(dbg.data_ptr())
+ops.mst_one_root(arc, lens); torch.cuda.synchronize()
+dbg.zero_()
+ops.mst_one_root(arc, lens); torch.cuda.synchronize()
+d = dbg.cpu().double()
+names = ["init", "argmax", "cycles", "lists", "edge+sum", "enter/leave+rec", "contract", "expand", "oneroot"]
+tot = d[:, :9].sum(1)
+print("runs/sentence mean %.2f max %d; levels/sentence mean %.1f max %d" % (d[:, 11].mean(), d[:, 11].max(), d[:, 10].mean(), d[:, 10].max()))
+print("cycles/sentence mean %.0f max %.0f" % (tot.mean(), tot.max()))
+for k, n in enumerate(names):
+    print(f"  {n:16s} share {100*d[:,k].sum()/tot.sum():5.1f}%   per level {d[:,k].sum()/max(d[:,10].sum(),1):8.0f} cyc")
