@@ -1,0 +1,196 @@
+"""Drop-in replacements with the reference's own names, signatures and return types, running on the HIP
+kernels.  Each mirrors one seam of SURVEY.md section 8b; argument meaning and error behaviour follow the
+reference (paths under /root/reference/phonlp).
+
+    from phonlp_amd.compat import viterbi_decode, chuliu_edmonds_one_root, CRFLoss, DeepBiaffineScorer, patch
+    model = phonlp.load(save_dir); patch(model); model.annotate(text=...)
+"""
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .heads import HeadWeights, TaskHeads, as_sentlens
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        raise RuntimeError("phonlp_amd needs a ROCm device: there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+# ---------------------------------------------------------------------------------------------------
+def viterbi_decode(scores, transition_params):
+    """ref models/common/crf.py:103-126.  scores: [l, T] numpy, transition_params: [T, T] numpy.
+    Returns (list of tag ids, best score) like the reference."""
+    dev = _dev()
+    s = torch.as_tensor(np.ascontiguousarray(scores, dtype=np.float32)).unsqueeze(0).to(dev)
+    tr = torch.as_tensor(np.ascontiguousarray(transition_params, dtype=np.float32)).to(dev)
+    lens = torch.tensor([s.shape[1]], dtype=torch.int32, device=dev)
+    tags, best = ops.crf_viterbi(s.contiguous(), tr.contiguous(), lens)
+    return tags[0].cpu().tolist(), np.float32(best[0].item())
+
+
+def chuliu_edmonds_one_root(scores):
+    """ref models/common/chuliu_edmonds.py:133-169.  scores: [l, l] numpy (rows = dependents).  Returns
+    int64[l].  Where the reference asserts (no finite single-root tree) this raises AssertionError too."""
+    dev = _dev()
+    s = torch.as_tensor(np.ascontiguousarray(scores, dtype=np.float32)).unsqueeze(0).to(dev)
+    l = s.shape[1]
+    heads, status = ops.mst_one_root(s.contiguous(), torch.tensor([l], dtype=torch.int32, device=dev))
+    if int(status[0].item()) != 0:
+        raise AssertionError("chuliu_edmonds_one_root: no finite single-root tree (reference asserts here)")
+    return heads[0].cpu().numpy().astype(np.int64)
+
+
+class CRFLoss(nn.Module):
+    """ref models/common/crf.py:13-100.  forward(inputs, masks, tag_indices) -> (loss, transitions); masks is
+    True on padding.  Inference-side only: no autograd through the kernels."""
+
+    def __init__(self, num_tag, batch_average=True):
+        super().__init__()
+        self._transitions = nn.Parameter(torch.zeros(num_tag, num_tag))
+        self._batch_average = batch_average
+
+    def forward(self, inputs, masks, tag_indices):
+        dev = _dev()
+        x = inputs.detach().to(dev, torch.float32).contiguous()
+        tr = self._transitions.detach().to(dev, torch.float32).contiguous()
+        ln, un, bi = ops.crf_log_partition(x, tr, masks.to(dev, torch.uint8).contiguous(), None,
+                                           tag_indices.to(dev, torch.int32).contiguous())
+        loss = (-(un + bi - ln)).sum()
+        if self._batch_average:
+            loss = loss / x.shape[0]
+        else:
+            loss = loss / (masks.eq(0).sum().to(dev) + 1e-8)
+        return loss, self._transitions
+
+
+class DeepBiaffineScorer(nn.Module):
+    """ref models/common/biaffine.py:68-85 with pairwise=True (the only form the reference instantiates).
+    forward(input1, input2) -> [B, L, L, O] (a non-contiguous view of [B, L, O, L] memory, like the
+    reference).  Both inputs must be the same tensor, as at every reference call site."""
+
+    def __init__(self, input1_size, input2_size, hidden_size, output_size, hidden_func=None, dropout=0, pairwise=True):
+        super().__init__()
+        if not pairwise or input1_size != input2_size:
+            raise NotImplementedError("only the pairwise, same-input form used by PhoNLP is implemented")
+        self.W1 = nn.Linear(input1_size, hidden_size)
+        self.W2 = nn.Linear(input2_size, hidden_size)
+        self.scorer = nn.Module()
+        self.scorer.W_bilin = nn.Module()
+        self.scorer.W_bilin.weight = nn.Parameter(torch.zeros(hidden_size + 1, hidden_size + 1, output_size))
+        self.scorer.W_bilin.bias = nn.Parameter(torch.zeros(output_size))  # loaded, never used (as the reference)
+        self._packed = None
+
+    def forward(self, input1, input2):
+        if input1 is not input2 and not (input1.data_ptr() == input2.data_ptr() and input1.shape == input2.shape):
+            raise NotImplementedError("phonlp_amd.DeepBiaffineScorer needs input1 is input2")
+        dev = _dev()
+        if self._packed is None:
+            g = lambda p: p.detach().to(dev, torch.float32).contiguous()
+            self._packed = ops.pack_scorer(g(self.W1.weight), g(self.W1.bias), g(self.W2.weight), g(self.W2.bias),
+                                           g(self.scorer.W_bilin.weight))
+        W12, b12, Wbt = self._packed
+        H, O = self.W1.weight.shape[0], self.scorer.W_bilin.weight.shape[2]
+        _, scores = ops.deep_biaffine_label(input1.detach().to(dev, torch.float32).contiguous(), W12, b12, Wbt, H, O, True)
+        return scores.permute(0, 1, 3, 2)
+
+
+# ---------------------------------------------------------------------------------------------------
+def _encode(model, tokens, first_subword):
+    """The part of the path that stays on PyTorch-ROCm: encoder + first-sub-word gather
+    (ref annotate_model.py:119-123 / :159-163), as one batched gather instead of a Python loop."""
+    dev = _dev()
+    enc_dev = next(model.phobert.parameters()).device  # wherever the caller keeps the encoder
+    emb = model.phobert(tokens.to(enc_dev))[2][-1]
+    idx = first_subword.to(enc_dev).unsqueeze(-1).expand(-1, -1, emb.size(-1))
+    return torch.gather(emb, 1, idx).float().to(dev).contiguous()
+
+
+def _tagger_forward(self, tokens_phobert, words_phobert, sentlens):
+    """ref annotate_model.py:113-152 -> ([LongTensor B x L], FloatTensor B x L x T)."""
+    out = self._amd_heads.tagger(_encode(self, tokens_phobert, words_phobert), sentlens)
+    return [out["pos_pred"].long()], out["ner_logits"]
+
+
+def _dep_forward(self, tokens_phobert, first_subword, sentlens):
+    """ref annotate_model.py:154-216 -> [np.float32 B x L x L log-probs, np.int64 B x L x L label arg-max]."""
+    out = self._amd_heads.parser(_encode(self, tokens_phobert, first_subword), sentlens)
+    return [out["arc_logp"].cpu().numpy(), out["label_argmax"].cpu().numpy().astype(np.int64)]
+
+
+def _annotate(self, text=None, input_file=None, output_file=None, batch_size=1, output_type=""):
+    """ref annotate_model.py:218-339, same arguments, return value and file formats.  Host-side batching uses the
+    model's own process_data_* / chunk_batches / get_batch; heads and decoders run on the GPU and only
+    O(B*L) integers come back per batch."""
+    if text is not None:
+        data = [text.split(" ")]
+    else:
+        with open(input_file) as f:
+            data = [ln.strip().split(" ") for ln in f if len(ln.strip()) != 0]
+        print("The number of sentences: ", len(data))
+    parser_batches = self.chunk_batches(self.process_data_parser(batch_text=data), batch_size)
+    tagger_batches = self.chunk_batches(self.process_data_tagger(batch_text=data), batch_size)
+    pos_all, ner_all, dep_all = [], [], []
+    with torch.no_grad():
+        for i in range(len(tagger_batches)):
+            tok, fsw, _, _, oidx, lens = self.get_batch(i, tagger_batches)
+            tok1, fsw1, _, _, oidx1, lens1 = self.get_batch(i, parser_batches)
+            out = self._amd_heads.annotate_batch(_encode(self, tok1, fsw1), lens1, _encode(self, tok, fsw), lens)
+            if int((out["mst_status"] != 0).sum().item()):
+                raise AssertionError("chuliu_edmonds_one_root: no finite single-root tree (reference asserts here)")
+            pos, ner = out["pos"].cpu().numpy(), out["ner"].cpu().numpy()
+            heads, rels = out["heads"].cpu().numpy(), out["rels"].cpu().numpy()
+            nb = len(lens)
+            dep_b = [[[str(int(heads[b][j])), r] for j, r in
+                      zip(range(1, lens1[b]), self.vocab["deprel"].unmap(rels[b][1:lens1[b]]))] for b in range(nb)]
+            pos_b = [[[u] for u in self.vocab["upos"].unmap(pos[b][:lens[b]])] for b in range(nb)]
+            ner_b = [self.vocab["ner_tag"].unmap(ner[b][:lens[b]]) for b in range(nb)]
+            dep_all += _unsort(dep_b, oidx1)
+            pos_all += _unsort(pos_b, oidx)
+            ner_all += _unsort(ner_b, oidx)
+    dep_all = _unsort(dep_all, self.data_orig_idx)
+    pos_all = _unsort(pos_all, self.data_orig_idx)
+    ner_all = _unsort(ner_all, self.data_orig_idx)
+    if text is not None:
+        return (data, pos_all, ner_all, dep_all)
+    with open(output_file, "w") as f:
+        for i, sent in enumerate(data):
+            for j, word in enumerate(sent):
+                p, n, (h, r) = pos_all[i][j][0], ner_all[i][j], dep_all[i][j]
+                if output_type == "conll":
+                    cols = [str(j + 1), word, "_", "_", p, "_", h, r, "_", n]
+                else:
+                    cols = [str(j + 1), word, p, n, h, r]
+                f.write("\t".join(cols) + "\n")
+            f.write("\n")
+
+
+def _unsort(items, original_index):
+    """Inverse of the reference's descending-length sort (ref models/common/utils.py:189-195)."""
+    assert len(items) == len(original_index), "Number of list elements must match with original indices."
+    out = [None] * len(items)
+    for item, k in zip(items, original_index):
+        out[k] = item
+    return out
+
+
+def patch(model, device=None, move_encoder=True):
+    """Swaps the heads of a reference `JointModel` (from `phonlp.load()`) for the HIP path, leaving
+    `model.phobert`, the vocab and the tokenizer untouched.  Rebinds `tagger_forward`, `dep_forward` and
+    `annotate`; `print_out` and the data helpers keep working unchanged.  `move_encoder=False` leaves the
+    encoder where it is (e.g. on the CPU, to reproduce CPU encoder outputs bit for bit)."""
+    dev = device or _dev()
+    if move_encoder:
+        model.phobert.to(dev)
+    sd = {k: v for k, v in model.state_dict().items() if not k.startswith("phobert.")}
+    weights = HeadWeights.from_state_dict(sd, dev, linearization=bool(model.args.get("linearization", True)),
+                                          distance=bool(model.args.get("distance", True)))
+    model._amd_heads = TaskHeads(weights)
+    model.tagger_forward = types.MethodType(_tagger_forward, model)
+    model.dep_forward = types.MethodType(_dep_forward, model)
+    model.annotate = types.MethodType(_annotate, model)
+    return model

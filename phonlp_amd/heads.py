@@ -139,11 +139,56 @@ class TaskHeads:
         return ops.crf_log_partition(ner_logits.contiguous(), self.w.trans, pm, ln, gd)
 
     # ---- the whole head path for one batch: what annotate() needs per batch (ref :256-287)
-    def annotate_batch(self, enc_dep, sentlens_dep, enc_tag, sentlens_tag) -> Dict[str, torch.Tensor]:
-        """Returns device int32 tensors: pos [B,Lt], ner [B,Lt], heads [B,Ld], rels [B,Ld], mst_status [B]."""
-        dep = self.parser(enc_dep, sentlens_dep)
-        tag = self.tagger(enc_tag, sentlens_tag)
-        ner, _ = ops.crf_viterbi(tag["ner_logits"], self.w.trans, tag["sentlens"])
-        heads, status = ops.mst_one_root(dep["arc_logp"], dep["sentlens"])
-        rels = ops.gather_labels(dep["label_argmax"], heads, dep["sentlens"])
+    def annotate_batch(self, enc_dep, sentlens_dep, enc_tag, sentlens_tag, overlap=True) -> Dict[str, torch.Tensor]:
+        """Returns device int32 tensors: pos [B,Lt], ner [B,Lt], heads [B,Ld], rels [B,Ld], mst_status [B].
+
+        With `overlap` the three independent chains run on separate HIP streams: the tagger chain (POS head,
+        NER emissions, Viterbi) and the MST decode (which only needs the arc log-probs) run beside the label
+        scorer's GEMMs.  The decoders are dependent chains that leave most of a CU idle; sharing the chip with
+        the MFMA-bound label path hides them.
+        """
+        if not overlap:
+            dep = self.parser(enc_dep, sentlens_dep)
+            tag = self.tagger(enc_tag, sentlens_tag)
+            ner, _ = ops.crf_viterbi(tag["ner_logits"], self.w.trans, tag["sentlens"])
+            heads, status = ops.mst_one_root(dep["arc_logp"], dep["sentlens"])
+            rels = ops.gather_labels(dep["label_argmax"], heads, dep["sentlens"])
+            return {"pos": tag["pos_pred"], "ner": ner, "heads": heads, "rels": rels, "mst_status": status}
+        w = self.w
+        main = torch.cuda.current_stream()
+        if not hasattr(self, "_side"):
+            self._side = (torch.cuda.Stream(), torch.cuda.Stream())
+        s_tag, s_mst = self._side
+        lens_d = as_sentlens(sentlens_dep, enc_dep.device)
+        lens_t = as_sentlens(sentlens_tag, enc_tag.device)
+        start = torch.cuda.Event()
+        start.record(main)
+        # tagger chain on its own stream
+        s_tag.wait_event(start)
+        with torch.cuda.stream(s_tag):
+            tag = self.tagger(enc_tag, lens_t)
+            ner, _ = ops.crf_viterbi(tag["ner_logits"], w.trans, lens_t)
+            tag_done = torch.cuda.Event()
+            tag_done.record(s_tag)
+        # parser chain up to the arc log-probs on the main stream
+        feat, _, _ = ops.pos_head(enc_dep.contiguous(), lens_d, w.upos_hid_w, w.upos_hid_b, w.upos_clf_w,
+                                  w.upos_clf_b, w.emb_dep)
+        hidden = ops.dep_hidden(feat, lens_d, w.dep_hid_w, w.dep_hid_b)
+        arc_logp, _ = ops.deep_biaffine_arc(hidden, w.arc_W12, w.arc_b12, w.arc_Wbt, w.H, w.n_arc_scorers,
+                                            w.linearization, w.distance, False)
+        arc_done = torch.cuda.Event()
+        arc_done.record(main)
+        # MST beside the label scorer
+        s_mst.wait_event(arc_done)
+        arc_logp.record_stream(s_mst)
+        with torch.cuda.stream(s_mst):
+            heads, status = ops.mst_one_root(arc_logp, lens_d)
+            mst_done = torch.cuda.Event()
+            mst_done.record(s_mst)
+        label_argmax, _ = ops.deep_biaffine_label(hidden, w.lab_W12, w.lab_b12, w.lab_Wbt, w.H, w.O, False)
+        main.wait_event(mst_done)
+        main.wait_event(tag_done)
+        for t in (heads, status, ner, tag["pos_pred"]):
+            t.record_stream(main)
+        rels = ops.gather_labels(label_argmax, heads, lens_d)
         return {"pos": tag["pos_pred"], "ner": ner, "heads": heads, "rels": rels, "mst_status": status}
