@@ -24,6 +24,17 @@ struct ProfScope {
 
 constexpr int kWave = 64;
 
+#ifdef __HIPCC__
+// Workgroup barrier that orders LDS traffic only (s_waitcnt lgkmcnt(0) + s_barrier): unlike __syncthreads()
+// it does not wait for global loads/stores in flight, so prefetches and epilogue stores stay asynchronous.
+// Use only where no global data is exchanged between the waves of the block across the barrier.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+#endif
+
 __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 __host__ __device__ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 

@@ -22,14 +22,24 @@ struct LinearArgs {
 // BM x BN block tile, WM x WN waves, each wave a (BM/WM) x (BN/WN) sub-tile.  TAG only names the
 // instantiation (TAG 1 = bilinear stage A of the label scorer, so profilers list it on its own row).
 //
+// PERSISTENT: the grid is (at most) two blocks per CU and every block walks a strided sequence of output
+// tiles.  K is short on this path (408 / 868), so a one-tile-per-block kernel spends ~17 % of its life in
+// block dispatch, the first slab's load latency and the epilogue (measured: 146 TFLOP/s for the bare
+// ds_read+MFMA loop at K=4096 vs 122 at K=408).  Here the first slab of the NEXT tile is fetched while the
+// last slab of the current one is multiplied, and blocks are never re-dispatched.
+//
 // K loop: two LDS slab buffers, ONE barrier per slab.  Iteration k issues the global loads of slab k+1,
-// multiplies slab k out of buffer k&1, then writes slab k+1 into buffer (k+1)&1; the barrier that ends the
-// iteration orders those writes before the next iteration's reads and this iteration's reads before the
-// writes of iteration k+1 into the same buffer.
-// Epilogue: bias and row-liveness are fetched up front in one batch, so the stores issue back to back
-// (a load between stores would make every s_waitcnt vmcnt(0) wait for the stores as well).
+// multiplies slab k out of buffer k&1, then writes slab k+1 into buffer (k+1)&1.  All slabs but the last
+// are full depth, so the loop has a single MFMA code path and the 64 accumulators stay pinned (a depth
+// switch inside the loop made hipcc shuttle them through v_accvgpr_write/read every slab, -9 %).
+// Epilogue: accumulators are transposed through a per-wave LDS patch so that every global store is a
+// 16-byte-per-lane row segment; bias / ReLU / padding mask fused.
+//
+// Tile order: block b belongs to XCD group x = b % 8 (blocks b, b+8, ... share an L2), local index
+// j = b / 8; in round i it takes tile (i*8 + x)*Gx + j of a sequence that walks 8-tile-tall column-major
+// groups, so the Gx blocks of one XCD work on one compact patch of tiles sharing A and B panels.
 template <int BM, int BN, int WM, int WN, int TAG>
-__global__ __launch_bounds__(WM *WN * 64) void linear_kernel(LinearArgs a) {
+__global__ __launch_bounds__(WM *WN * 64, 2) void linear_kernel(LinearArgs a) {
     constexpr int THREADS = WM * WN * 64;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int BUF = (BM + BN) * PITCH;
@@ -37,106 +47,158 @@ __global__ __launch_bounds__(WM *WN * 64) void linear_kernel(LinearArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    int tm, tn;
-    tile_coords(blockIdx.x, gridDim.x, a.num_m, a.num_n, tm, tn);
-    const int m0 = tm * BM, n0 = tn * BN;
-    const float *Xt = a.X + (long)m0 * a.ldx;
-    const float *Wt = a.W + (long)n0 * a.ldw;
-    const int mv = a.M - m0, nv = a.N - n0;
+    const int ntiles = a.num_m * a.num_n;
+    const int gx = gridDim.x >> 3;  // blocks per XCD group (gridDim.x is a multiple of 8, or == ntiles < 8)
+    const int xg = blockIdx.x & 7, jl = blockIdx.x >> 3;
+    const int nslab = (a.K + BK - 1) / BK;
+
+    // tile sequence index of this block in `round`.  With gridDim.x == ntiles (the default: blocks of other
+    // kernels on other streams can then interleave, which a statically partitioned persistent grid cannot
+    // tolerate) there is one round and the map is the bijective "contiguous chunk per XCD group" remap.
+    auto tile_of = [&](int round, int &m0, int &n0) -> bool {
+        long t;
+        if ((int)gridDim.x == ntiles) {
+            if (round > 0) return false;
+            const int q = ntiles >> 3, r = ntiles & 7;
+            t = (xg < r ? xg * (q + 1) : r * (q + 1) + (xg - r) * q) + jl;
+        } else {
+            t = ((long)round * 8 + xg) * gx + jl;
+        }
+        if (t >= ntiles) return false;
+        constexpr int GM = 8;
+        const int per_group = GM * a.num_n;
+        const int g = (int)(t / per_group);
+        const int first_m = g * GM;
+        const int gsz = (a.num_m - first_m) < GM ? (a.num_m - first_m) : GM;
+        const int in = (int)(t - (long)g * per_group);
+        m0 = (first_m + in % gsz) * BM;
+        n0 = (in / gsz) * BN;
+        return true;
+    };
 
     f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
     Slab<BM, THREADS> ra;
     Slab<BN, THREADS> rb;
-    slab_load(ra, Xt, a.ldx, mv, 0, a.K, tid);
-    slab_load(rb, Wt, a.ldw, nv, 0, a.K, tid);
-    slab_store(ra, lds, tid);
-    slab_store(rb, lds + BM * PITCH, tid);
-    __syncthreads();
-    int cur = 0;
-    for (int k0 = 0; k0 < a.K; k0 += BK) {
-        const bool more = k0 + BK < a.K;
-        if (more) {
-            slab_load(ra, Xt, a.ldx, mv, k0 + BK, a.K, tid);
-            slab_load(rb, Wt, a.ldw, nv, k0 + BK, a.K, tid);
-        }
-        const float *As = lds + cur * BUF, *Bs = As + BM * PITCH;
-        mma_slab<TM, TN>(As + wm * TM * 32 * PITCH, Bs + wn * TN * 32 * PITCH, lane, acc, slab_depth(k0, a.K));
-        if (more) {
+    int m0 = 0, n0 = 0, round = 0;
+    bool have = tile_of(0, m0, n0);
+    if (have) {
+        slab_load(ra, a.X + (long)m0 * a.ldx, a.ldx, a.M - m0, 0, a.K, tid);
+        slab_load(rb, a.W + (long)n0 * a.ldw, a.ldw, a.N - n0, 0, a.K, tid);
+    }
+    while (have) {
+        const float *Xt = a.X + (long)m0 * a.ldx;
+        const float *Wt = a.W + (long)n0 * a.ldw;
+        const int mv = a.M - m0, nv = a.N - n0;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        slab_store(ra, lds, tid);
+        slab_store(rb, lds + BM * PITCH, tid);
+        __syncthreads();
+        int cur = 0;
+        for (int sidx = 0; sidx < nslab - 1; ++sidx) {
+            const int k1 = (sidx + 1) * BK;
+            slab_load(ra, Xt, a.ldx, mv, k1, a.K, tid);
+            slab_load(rb, Wt, a.ldw, nv, k1, a.K, tid);
+            const float *As = lds + cur * BUF, *Bs = As + BM * PITCH;
+            mma_slab_d<TM, TN, 32>(As + wm * TM * 32 * PITCH, Bs + wn * TN * 32 * PITCH, lane, acc);
             float *An = lds + (cur ^ 1) * BUF;
             slab_store(ra, An, tid);
             slab_store(rb, An + BM * PITCH, tid);
+            __syncthreads();
+            cur ^= 1;
         }
-        __syncthreads();
-        cur ^= 1;
-    }
+        // last slab of this tile; meanwhile fetch the first slab of the next one
+        int m1 = 0, n1 = 0;
+        const bool have1 = tile_of(round + 1, m1, n1);
+        if (have1) {
+            slab_load(ra, a.X + (long)m1 * a.ldx, a.ldx, a.M - m1, 0, a.K, tid);
+            slab_load(rb, a.W + (long)n1 * a.ldw, a.ldw, a.N - n1, 0, a.K, tid);
+        }
+        {
+            const float *As = lds + cur * BUF, *Bs = As + BM * PITCH;
+            mma_slab<TM, TN>(As + wm * TM * 32 * PITCH, Bs + wn * TN * 32 * PITCH, lane, acc,
+                             slab_depth((nslab - 1) * BK, a.K));
+            lds_barrier();  // not __syncthreads(): the next tile's prefetch must stay in flight
+        }
 
-    // ---- epilogue: each wave transposes its accumulators through its own LDS patch so that every global
-    // store is a 16-byte-per-lane row segment (a 32x32 accumulator register is one dword per lane: 4x the
-    // store instructions and quarter-line writes if stored directly).
-    constexpr int WCOLS = TN * 32, EP = WCOLS + 4;
-    static_assert(WM * WN * 32 * EP <= 2 * BUF, "epilogue patch must fit the slab buffers");
-    float *ep = lds + wave * 32 * EP;
-    constexpr int LPR = WCOLS / 4;   // lanes per row
-    constexpr int RPI = 64 / LPR;    // rows per wave-instruction
-    const int c4 = (lane % LPR) * 4;
-    const int col = n0 + wn * WCOLS + c4;
-    const int rsub = lane / LPR;
-    const bool vec_ok = ((a.ldy & 3) == 0) && (((uintptr_t)a.Y & 15) == 0) && (col + 3 < a.N);
-    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (a.bias) {
-        if (col < a.N) bv.x = a.bias[col];
-        if (col + 1 < a.N) bv.y = a.bias[col + 1];
-        if (col + 2 < a.N) bv.z = a.bias[col + 2];
-        if (col + 3 < a.N) bv.w = a.bias[col + 3];
-    }
-    unsigned live[TM];
+        // ---- epilogue
+        constexpr int WCOLS = TN * 32, EP = WCOLS + 4;
+        static_assert(WM * WN * 32 * EP <= 2 * BUF, "epilogue patch must fit the slab buffers");
+        float *ep = lds + wave * 32 * EP;
+        constexpr int LPR = WCOLS / 4;   // lanes per row
+        constexpr int RPI = 64 / LPR;    // rows per wave-instruction
+        const int c4 = (lane % LPR) * 4;
+        const int col = n0 + wn * WCOLS + c4;
+        const int rsub = lane / LPR;
+        const bool vec_ok = ((a.ldy & 3) == 0) && (((uintptr_t)a.Y & 15) == 0) && (col + 3 < a.N);
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.bias) {
+            if (col < a.N) bv.x = a.bias[col];
+            if (col + 1 < a.N) bv.y = a.bias[col + 1];
+            if (col + 2 < a.N) bv.z = a.bias[col + 2];
+            if (col + 3 < a.N) bv.w = a.bias[col + 3];
+        }
+        unsigned live[TM];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        live[i] = 0xFFFFFFFFu;
-        if (a.sentlens) {
-            live[i] = 0;
+        for (int i = 0; i < TM; ++i) {
+            live[i] = 0xFFFFFFFFu;
+            if (a.sentlens) {
+                live[i] = 0;
+#pragma unroll
+                for (int it = 0; it < 32 / RPI; ++it) {
+                    const int row = m0 + (wm * TM + i) * 32 + it * RPI + rsub;
+                    if (row < a.M && (row % a.L) < a.sentlens[row / a.L]) live[i] |= 1u << it;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ep[acc_row(r, lane) * EP + j * 32 + (lane & 31)] = acc[i][j][r];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
             for (int it = 0; it < 32 / RPI; ++it) {
-                const int row = m0 + (wm * TM + i) * 32 + it * RPI + rsub;
-                if (row < a.M && (row % a.L) < a.sentlens[row / a.L]) live[i] |= 1u << it;
+                const int lrow = it * RPI + rsub;
+                const int row = m0 + (wm * TM + i) * 32 + lrow;
+                float4 v = *reinterpret_cast<const float4 *>(ep + lrow * EP + c4);
+                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (!((live[i] >> it) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row >= a.M || col >= a.N) continue;
+                float *y = a.Y + (long)row * a.ldy + col;
+                if (vec_ok) {
+                    *reinterpret_cast<float4 *>(y) = v;
+                } else {
+                    y[0] = v.x;
+                    if (col + 1 < a.N) y[1] = v.y;
+                    if (col + 2 < a.N) y[2] = v.z;
+                    if (col + 3 < a.N) y[3] = v.w;
+                }
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
+        lds_barrier();  // the patches alias the slab buffers the next tile is about to fill; the tile's global
+                        // stores are NOT waited for (a full barrier would expose their write latency per tile)
+        have = have1;
+        m0 = m1;
+        n0 = n1;
+        ++round;
     }
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) ep[acc_row(r, lane) * EP + j * 32 + (lane & 31)] = acc[i][j][r];
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#pragma unroll
-        for (int it = 0; it < 32 / RPI; ++it) {
-            const int lrow = it * RPI + rsub;
-            const int row = m0 + (wm * TM + i) * 32 + lrow;
-            float4 v = *reinterpret_cast<const float4 *>(ep + lrow * EP + c4);
-            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-            if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            if (!((live[i] >> it) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row >= a.M || col >= a.N) continue;
-            float *y = a.Y + (long)row * a.ldy + col;
-            if (vec_ok) {
-                *reinterpret_cast<float4 *>(y) = v;
-            } else {
-                y[0] = v.x;
-                if (col + 1 < a.N) y[1] = v.y;
-                if (col + 2 < a.N) y[2] = v.z;
-                if (col + 3 < a.N) y[3] = v.w;
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    }
+}
+
+// Grid size.  One block per tile by default.  PHONLP_GEMM_PERSISTENT=1 selects a persistent grid of two blocks
+// per CU walking strided tiles (+3 % when the GEMM has the chip to itself, but its static partition stalls
+// when kernels of other streams hold CUs, which is how TaskHeads.annotate_batch runs).
+static int persistent_grid(int ntiles) {
+    static const bool persistent = getenv("PHONLP_GEMM_PERSISTENT") && atoi(getenv("PHONLP_GEMM_PERSISTENT")) == 1;
+    if (!persistent || ntiles < 512) return ntiles;
+    return 512;
 }
 
 int launch_linear(const char *tag, const float *X, long ldx, const float *W, long ldw, const float *bias, float *Y, long ldy, int M,
@@ -148,29 +210,16 @@ int launch_linear(const char *tag, const float *X, long ldx, const float *W, lon
     LinearArgs a{X, W, bias, Y, sentlens, ldx, ldw, ldy, M, N, K, L, relu, 0, 0};
     const bool stage_a = tag && !strcmp(tag, "linear:label_stage_a");
     ProfScope ps(tag, stream);
+    a.num_m = ceil_div(M, 128);
     if (N <= 64) {
-        a.num_m = ceil_div(M, 128);
         a.num_n = ceil_div(N, 32);
-        hipLaunchKernelGGL((linear_kernel<128, 32, 4, 1, 0>), dim3(a.num_m * a.num_n), dim3(256), 0, stream, a);
-    } else if (getenv("PHONLP_GEMM_CFG") && atoi(getenv("PHONLP_GEMM_CFG")) == 1) {
-        a.num_m = ceil_div(M, 128);
-        a.num_n = ceil_div(N, 128);
-        hipLaunchKernelGGL((linear_kernel<128, 128, 2, 4, 2>), dim3(a.num_m * a.num_n), dim3(512), 0, stream, a);
-    } else if (getenv("PHONLP_GEMM_CFG") && atoi(getenv("PHONLP_GEMM_CFG")) == 2) {
-        a.num_m = ceil_div(M, 256);
-        a.num_n = ceil_div(N, 128);
-        hipLaunchKernelGGL((linear_kernel<256, 128, 4, 2, 2>), dim3(a.num_m * a.num_n), dim3(512), 0, stream, a);
-    } else if (getenv("PHONLP_GEMM_CFG") && atoi(getenv("PHONLP_GEMM_CFG")) == 3) {
-        a.num_m = ceil_div(M, 128);
-        a.num_n = ceil_div(N, 64);
-        hipLaunchKernelGGL((linear_kernel<128, 64, 4, 1, 2>), dim3(a.num_m * a.num_n), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL((linear_kernel<128, 32, 4, 1, 0>), dim3(persistent_grid(a.num_m * a.num_n)), dim3(256), 0,
+                           stream, a);
     } else {
-        a.num_m = ceil_div(M, 128);
         a.num_n = ceil_div(N, 128);
-        if (stage_a)
-            hipLaunchKernelGGL((linear_kernel<128, 128, 2, 2, 1>), dim3(a.num_m * a.num_n), dim3(256), 0, stream, a);
-        else
-            hipLaunchKernelGGL((linear_kernel<128, 128, 2, 2, 0>), dim3(a.num_m * a.num_n), dim3(256), 0, stream, a);
+        const dim3 g(persistent_grid(a.num_m * a.num_n));
+        if (stage_a) hipLaunchKernelGGL((linear_kernel<128, 128, 2, 2, 1>), g, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((linear_kernel<128, 128, 2, 2, 0>), g, dim3(256), 0, stream, a);
     }
     return check_launch("linear_kernel");
 }

@@ -56,15 +56,6 @@ struct MstArgs {
 
 #define NEG_INF_D (-__builtin_inf())
 
-// Workgroup barrier that orders LDS traffic only: the per-level expansion records are stored to global
-// memory and not read again before the (full) barrier that precedes the expansion, so the contraction
-// loop need not wait for those stores to be acknowledged at every barrier.
-__device__ __forceinline__ void lds_barrier() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
-
 // numpy's float64 pairwise add-reduction order (verified against numpy 2.2, n = 1..1000).
 __device__ inline double np_sum_block(const double *a, int n) {
     if (n < 8) {
