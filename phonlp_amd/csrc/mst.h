@@ -1,0 +1,74 @@
+// Shared declarations of the two Chu-Liu-Edmonds kernels (mst.hip: block-synchronous, any L <= 1024;
+// mst_wave.hip: wave-synchronous level loop, used when the float64 matrix fits LDS).
+#pragma once
+#include <limits.h>
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace phonlp {
+
+struct MstArgs {
+    const float *arc;
+    const int32_t *sentlens;
+    int32_t *heads;
+    int32_t *status;
+    uint16_t *stack;
+    double *gmat;
+    long stack_stride;  // u16 per sentence
+    long gmat_stride;   // doubles per sentence
+    int B, L, pitch, lvl_stride;
+    long long *dbg;  // diagnostic builds only (-DMST_STAMPS): 16 counters per sentence
+};
+
+#ifdef MST_STAMPS
+#define STAMP(k)                                              \
+    do {                                                      \
+        if (tid == 0) {                                       \
+            const long long now_ = clock64();                 \
+            stamp_acc[k] += now_ - stamp_t;                   \
+            stamp_t = now_;                                   \
+        }                                                     \
+    } while (0)
+#else
+#define STAMP(k) do {} while (0)
+#endif
+
+#define NEG_INF_D (-__builtin_inf())
+
+// numpy's float64 pairwise add-reduction order (verified against numpy 2.2, n = 1..1000).
+__device__ inline double np_sum_block(const double *a, int n) {
+    if (n < 8) {
+        double r = 0.0;
+        for (int i = 0; i < n; ++i) r += a[i];
+        return r;
+    }
+    double r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
+    int i = 8;
+    for (; i < n - (n % 8); i += 8) {
+        r0 += a[i]; r1 += a[i + 1]; r2 += a[i + 2]; r3 += a[i + 3];
+        r4 += a[i + 4]; r5 += a[i + 5]; r6 += a[i + 6]; r7 += a[i + 7];
+    }
+    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < n; ++i) res += a[i];
+    return res;
+}
+template <int DEPTH>
+__device__ inline double np_sum(const double *a, int n) {
+    if (n <= 128) return np_sum_block(a, n);
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_sum<DEPTH - 1>(a, n2) + np_sum<DEPTH - 1>(a + n2, n - n2);
+}
+template <>
+__device__ inline double np_sum<0>(const double *a, int n) { return np_sum_block(a, n); }
+
+
+inline size_t mst_lvl_stride(int L) { return 4 * (size_t)L + 8; }
+inline int mst_pitch(int L) { return L | 1; }
+
+// mst_wave.hip
+bool mst_wave_fits(int L);
+int launch_mst_wave(const MstArgs &a, hipStream_t stream);
+
+}  // namespace phonlp

@@ -21,67 +21,9 @@
 // Every float64 operation matches the reference's: (s - edge) + total (:84), numpy's pairwise
 // summation order for cycle_scores.sum() (:75) and tree_probs.sum() (:158), strict '>' for
 // first-maximum ties.
-#include <limits.h>
-#include <stdlib.h>
-
-#include "common.h"
+#include "mst.h"
 
 namespace phonlp {
-
-struct MstArgs {
-    const float *arc;
-    const int32_t *sentlens;
-    int32_t *heads;
-    int32_t *status;
-    uint16_t *stack;
-    double *gmat;
-    long stack_stride;  // u16 per sentence
-    long gmat_stride;   // doubles per sentence
-    int B, L, pitch, lvl_stride;
-    long long *dbg;  // diagnostic builds only (-DMST_STAMPS): 16 counters per sentence
-};
-
-#ifdef MST_STAMPS
-#define STAMP(k)                                              \
-    do {                                                      \
-        if (tid == 0) {                                       \
-            const long long now_ = clock64();                 \
-            stamp_acc[k] += now_ - stamp_t;                   \
-            stamp_t = now_;                                   \
-        }                                                     \
-    } while (0)
-#else
-#define STAMP(k) do {} while (0)
-#endif
-
-#define NEG_INF_D (-__builtin_inf())
-
-// numpy's float64 pairwise add-reduction order (verified against numpy 2.2, n = 1..1000).
-__device__ inline double np_sum_block(const double *a, int n) {
-    if (n < 8) {
-        double r = 0.0;
-        for (int i = 0; i < n; ++i) r += a[i];
-        return r;
-    }
-    double r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
-    int i = 8;
-    for (; i < n - (n % 8); i += 8) {
-        r0 += a[i]; r1 += a[i + 1]; r2 += a[i + 2]; r3 += a[i + 3];
-        r4 += a[i + 4]; r5 += a[i + 5]; r6 += a[i + 6]; r7 += a[i + 7];
-    }
-    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
-    for (; i < n; ++i) res += a[i];
-    return res;
-}
-template <int DEPTH>
-__device__ inline double np_sum(const double *a, int n) {
-    if (n <= 128) return np_sum_block(a, n);
-    int n2 = n / 2;
-    n2 -= n2 % 8;
-    return np_sum<DEPTH - 1>(a, n2) + np_sum<DEPTH - 1>(a + n2, n - n2);
-}
-template <>
-__device__ inline double np_sum<0>(const double *a, int n) { return np_sum_block(a, n); }
 
 // scalars kept in LDS
 enum { SC_M = 0, SC_NEXT, SC_NROOT, SC_FINITE, SC_NNEED, SC_TAKE, SC_COUNT = 16 };
@@ -398,9 +340,7 @@ __global__ __launch_bounds__(1024) void mst_kernel(MstArgs a) {
 }
 
 static size_t mst_aux_bytes(int L) { return (size_t)L * 8 * 3 + 32 + (size_t)L * 4 * 17 + (SC_COUNT + 16) * 4; }
-static int mst_pitch(int L) { return L | 1; }
 static bool mst_fits_lds(int L) { return (size_t)L * mst_pitch(L) * 8 + mst_aux_bytes(L) <= 160 * 1024; }
-static int mst_lvl_stride(int L) { return 4 * L + 8; }
 
 }  // namespace phonlp
 
@@ -440,6 +380,7 @@ extern "C" int phonlp_mst_one_root(const float *arc, const int32_t *sentlens, in
         attr_set = true;
     }
     ProfScope ps("mst", as_stream(stream));
+    if (mst_wave_fits(L) && !getenv("PHONLP_MST_BLOCKSYNC")) return launch_mst_wave(a, as_stream(stream));
     if (in_lds) {
         lds += (size_t)L * a.pitch * sizeof(double);
         hipLaunchKernelGGL(mst_kernel<true>, dim3(B), dim3(threads), lds, as_stream(stream), a);

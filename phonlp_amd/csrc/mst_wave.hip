@@ -1,0 +1,401 @@
+// Chu-Liu-Edmonds single-root MST, wave-synchronous variant (used when the float64 matrix fits LDS, L <= ~134).
+//
+// Same algorithm, same arithmetic and same tie-breaking as mst.hip (see its header for why the slot map, the
+// "largest minimum index" cycle choice and the incremental row rescans reproduce ref
+// models/common/chuliu_edmonds.py bit for bit).  What differs is who runs the level loop.  On the synthetic
+// head distribution a sentence of 128 nodes needs ~100-130 contraction levels per run, each a dozen tiny
+// dependent phases; with four waves every phase boundary is an s_barrier, and the block-synchronous kernel
+// spends ~12k cycles per level mostly waiting.  Here the whole workgroup only loads the matrix and does the
+// level-0 arg-max (the two O(l^2) steps); then ONE wavefront runs the contraction loop, the expansion and the
+// single-root scoring with no barrier at all: LDS operations of a wave execute in program order, so a
+// wavefront-scope fence (a compiler ordering point, no instruction) is all a phase boundary needs.
+// Lane i owns nodes i, i+64, ... (NPL per lane); lists are built with ballot/popcount prefix ranks.
+//
+// Expansion records live on a byte stack in the LDS left over after the matrix (2n bytes per level: cycle
+// members, their heads, and per outside node the two arg-max picks; the outside-node list is rebuilt from the
+// member list).  A level that does not fit spills to the caller's global workspace; its loads are slower, the
+// result is the same.
+#include "mst.h"
+
+namespace phonlp {
+
+#define WFENCE() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
+
+enum { WS_NEXT = 0, WS_DONE, WS_COUNT = 8 };
+
+struct WaveLayout {
+    size_t off_edge, off_int, off_stack, total;
+    int stack_cap;
+};
+constexpr int kIntArrays = 16;
+static WaveLayout wave_layout(int L) {
+    WaveLayout w;
+    const size_t mat = (size_t)L * mst_pitch(L) * sizeof(double);
+    w.off_edge = mat;
+    w.off_int = w.off_edge + (size_t)L * sizeof(double);
+    w.off_stack = w.off_int + ((size_t)kIntArrays * L + WS_COUNT) * sizeof(int);
+    const long cap = 160L * 1024 - (long)w.off_stack;
+    w.stack_cap = cap > 0 ? (int)(cap & ~15L) : 0;
+    w.total = w.off_stack + w.stack_cap;
+    return w;
+}
+bool mst_wave_fits(int L) { return L <= 255 && wave_layout(L).stack_cap >= 4 * L; }
+
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int t = __shfl_xor(v, o);
+        v = t > v ? t : v;
+    }
+    return v;
+}
+
+// first-maximum arg-max of logical row `row` over logical columns [0, n), by the 16 lanes of a group
+__device__ __forceinline__ int row_argmax16(const double *S, int pitch, const int *node, int row, int n, int sub) {
+    const int rs = node[row];
+    double bv = NEG_INF_D;
+    int bi = INT_MAX;
+    if (sub < n) { bv = S[(long)rs * pitch + node[sub]]; bi = sub; }
+    for (int c = sub + 16; c < n; c += 16) {
+        const double v = S[(long)rs * pitch + node[c]];
+        if (v > bv) { bv = v; bi = c; }
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+        const double v2 = __shfl_xor(bv, o, 16);
+        const int i2 = __shfl_xor(bi, o, 16);
+        if (v2 > bv || (v2 == bv && i2 < bi)) { bv = v2; bi = i2; }
+    }
+    return bi;
+}
+
+template <int NPL>
+__global__ __launch_bounds__(256) void mst_wave_kernel(MstArgs a, int stack_cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6, sub = lane & 15;
+    const int L = a.L, pitch = a.pitch;
+    int l = a.sentlens[b];
+    if (l > L) l = L;
+    int32_t *hout = a.heads + (long)b * L;
+    for (int t = tid; t < L; t += 256) hout[t] = 0;
+    if (l <= 1) {
+        if (tid == 0) a.status[b] = l == 1 ? PHONLP_MST_NO_FINITE_TREE : PHONLP_MST_OK;
+        return;
+    }
+    double *S = reinterpret_cast<double *>(smem_raw);
+    double *edge = S + (long)L * pitch;
+    int *node = reinterpret_cast<int *>(edge + L);
+    int *hdA = node + L, *hdB = hdA + L, *pk0 = hdB + L, *pk1 = pk0 + L, *flag = pk1 + L, *incyc = flag + L;
+    int *rankr = incyc + L, *cyc = rankr + L, *rest = cyc + L, *needl = rest + L, *tree0 = needl + L;
+    int *besttree = tree0 + L, *lvl_n = besttree + L, *lvl_c = lvl_n + L, *lvl_off = lvl_c + L;
+    int *sc = lvl_off + L;
+    unsigned char *lstack = reinterpret_cast<unsigned char *>(sc + WS_COUNT);
+    unsigned char *gstack = reinterpret_cast<unsigned char *>(a.stack + (long)b * a.stack_stride);
+    const int gstride = a.lvl_stride * 2;  // bytes per spilled level (>= 2n)
+    const float *arc = a.arc + (long)b * L * L;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+#define SM(r, c) S[(long)(r) * pitch + (c)]
+
+    int root = -1;
+    double best_score = NEG_INF_D;  // wave 0 only
+    int have_best = 0, err = 0;
+
+    for (;;) {
+        // ---- whole workgroup: load + edit the matrix (ref :136, :143-149, :55-57), level-0 arg-max (ref :58)
+        for (int idx = tid; idx < l * l; idx += 256) {
+            const int i = idx / l, j = idx - i * l;
+            double v = (double)arc[(long)i * L + j];
+            if (root >= 1) {
+                if (j == 0 && i >= 1) v = NEG_INF_D;
+                if (i == root) v = j == 0 ? 0.0 : NEG_INF_D;
+            }
+            if (i == j) v = NEG_INF_D;
+            if (i == 0) v = j == 0 ? 0.0 : NEG_INF_D;
+            SM(i, j) = v;
+        }
+        for (int t = tid; t < l; t += 256) node[t] = t;
+        __syncthreads();
+        for (int row = tid >> 4; row < l; row += 16) {
+            const int bi = row_argmax16(S, pitch, node, row, l, sub);
+            if (sub == 0) hdA[row] = bi;
+        }
+        __syncthreads();
+
+        if (wave == 0) {
+            int n = l, levels = 0, used = 0;
+            // ------------------------------------------------------------------ contraction loop
+            for (;;) {
+                // cycles by pointer doubling on packed (min index << 16 | pointer) words
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) {
+                    const int v = lane + 64 * q;
+                    if (v < n) { pk0[v] = hdA[v] | (v << 16); flag[v] = 0; }
+                }
+                WFENCE();
+                int *pc = pk0, *pn = pk1;
+                for (int span = 1; span < n; span <<= 1) {
+#pragma unroll
+                    for (int q = 0; q < NPL; ++q) {
+                        const int v = lane + 64 * q;
+                        if (v < n) {
+                            const int x = pc[v];
+                            const int y = pc[x & 0xFFFF];
+                            const int mx = x >> 16, my = y >> 16;
+                            pn[v] = (y & 0xFFFF) | ((mx < my ? mx : my) << 16);
+                        }
+                    }
+                    WFENCE();
+                    int *t = pc; pc = pn; pn = t;
+                }
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) {
+                    const int v = lane + 64 * q;
+                    if (v < n) flag[pc[v] & 0xFFFF] = 1;
+                }
+                WFENCE();
+                int M = 0;
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) {
+                    const int v = lane + 64 * q;
+                    if (v < n && flag[v]) { const int m = pc[v] >> 16; M = m > M ? m : M; }
+                }
+                M = wave_max_i(M);
+                if (M == 0) break;
+                if (levels >= l) { err = 1; break; }
+                // the chosen cycle; member / outside lists in ascending logical order
+                int c = 0;
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) {
+                    const int v = lane + 64 * q;
+                    const int f = (v < n && flag[v] && (pc[v] >> 16) == M) ? 1 : 0;
+                    const unsigned long long bal = __ballot(f);
+                    const int rc = c + __popcll(bal & lt_mask);
+                    if (v < n) {
+                        incyc[v] = f;
+                        rankr[v] = v - rc;
+                        if (f) cyc[rc] = v; else rest[v - rc] = v;
+                    }
+                    c += __popcll(bal);
+                }
+                const int k = n - c;
+                WFENCE();
+                // cycle edge scores and their numpy-ordered sum (ref :73-75)
+                for (int x = lane; x < c; x += 64) {
+                    const int v = cyc[x];
+                    edge[x] = SM(node[v], node[hdA[v]]);
+                }
+                WFENCE();
+                const double total = np_sum<4>(edge, c);  // every lane, broadcast LDS reads
+                // expansion record of this level
+                unsigned char *rec;
+                if (used + 2 * n <= stack_cap) { rec = lstack + used; lvl_off[levels] = used; used += 2 * n; }
+                else { rec = gstack + (long)levels * gstride; lvl_off[levels] = -1; }
+                if (lane == 0) { lvl_n[levels] = n; lvl_c[levels] = c; }
+                unsigned char *r_cyc = rec, *r_hd = rec + c, *r_ep = rec + 2 * c, *r_lp = r_ep + k;
+                for (int x = lane; x < c; x += 64) { r_cyc[x] = (unsigned char)cyc[x]; r_hd[x] = (unsigned char)hdA[cyc[x]]; }
+                // best way into the cycle from every outside node / best head inside it (ref :84-99)
+                const int ms = node[cyc[0]];
+                int my_slot[NPL], my_newhead[NPL], my_need[NPL];
+                double my_ev[NPL], my_lv[NPL];
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) {
+                    const int x = lane + 64 * q;
+                    my_slot[q] = 0; my_newhead[q] = 0; my_need[q] = 0; my_ev[q] = 0.0; my_lv[q] = 0.0;
+                    if (x < k) {
+                        const int old = rest[x];
+                        const int slot = node[old];
+                        const int c0 = node[cyc[0]];
+                        double be = (SM(c0, slot) - edge[0]) + total;
+                        double bl = SM(slot, c0);
+                        int ae = 0, al = 0;
+                        for (int m = 1; m < c; ++m) {
+                            const int cs = node[cyc[m]];
+                            const double ve = (SM(cs, slot) - edge[m]) + total;
+                            if (ve > be) { be = ve; ae = m; }
+                            const double vl = SM(slot, cs);
+                            if (vl > bl) { bl = vl; al = m; }
+                        }
+                        my_slot[q] = slot; my_ev[q] = be; my_lv[q] = bl;
+                        r_ep[x] = (unsigned char)ae;
+                        r_lp[x] = (unsigned char)al;
+                        const int h = hdA[old];
+                        if (incyc[h]) my_need[q] = 1; else my_newhead[q] = rankr[h];
+                    }
+                }
+                WFENCE();
+                // contract in place; rows that pointed into the cycle (and the metanode) go on the rescan list
+                int nneed = 0;
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) {
+                    const int x = lane + 64 * q;
+                    const int nd = (x < k && my_need[q]) ? 1 : 0;
+                    if (x < k) {
+                        SM(ms, my_slot[q]) = my_ev[q];
+                        SM(my_slot[q], ms) = my_lv[q];
+                        node[x] = my_slot[q];
+                        hdA[x] = my_newhead[q];
+                    }
+                    const unsigned long long bal = __ballot(nd);
+                    if (nd) needl[nneed + __popcll(bal & lt_mask)] = x;
+                    nneed += __popcll(bal);
+                }
+                if (lane == 0) { SM(ms, ms) = NEG_INF_D; node[k] = ms; needl[nneed] = k; }
+                ++nneed;
+                n = k + 1;
+                ++levels;
+                WFENCE();
+                for (int p = 0; p < nneed; p += 4) {
+                    const int idx = p + (lane >> 4);
+                    const int row = idx < nneed ? needl[idx] : 0;
+                    const int bi = row_argmax16(S, pitch, node, row, n, sub);
+                    if (idx < nneed && sub == 0) hdA[row] = bi;
+                }
+                WFENCE();
+            }
+            // ------------------------------------------------------------------ expansion (ref :105-128)
+            int *cur = hdA, *oth = hdB;
+            if (!err) {
+                __threadfence_block();  // spilled records (global stores of this wave) before they are re-read
+                for (int lev = levels - 1; lev >= 0; --lev) {
+                    const int np_ = lvl_n[lev], c = lvl_c[lev], k = np_ - c;
+                    const int off = lvl_off[lev];
+                    const unsigned char *rec = off >= 0 ? lstack + off : gstack + (long)lev * gstride;
+                    const unsigned char *r_cyc = rec, *r_hd = rec + c, *r_ep = rec + 2 * c, *r_lp = r_ep + k;
+#pragma unroll
+                    for (int q = 0; q < NPL; ++q) {
+                        const int v = lane + 64 * q;
+                        if (v < np_) flag[v] = 0;
+                    }
+                    WFENCE();
+                    for (int x = lane; x < c; x += 64) flag[r_cyc[x]] = 1;
+                    WFENCE();
+                    int base = 0;
+#pragma unroll
+                    for (int q = 0; q < NPL; ++q) {
+                        const int v = lane + 64 * q;
+                        const int f = (v < np_ && flag[v]) ? 1 : 0;
+                        const unsigned long long bal = __ballot(f);
+                        const int rc = base + __popcll(bal & lt_mask);
+                        if (v < np_ && !f) rest[v - rc] = v;
+                        base += __popcll(bal);
+                    }
+                    WFENCE();
+#pragma unroll
+                    for (int q = 0; q < NPL; ++q) {
+                        const int x = lane + 64 * q;
+                        if (x < k) {
+                            const int sx = cur[x];
+                            oth[rest[x]] = sx < k ? rest[sx] : (int)r_cyc[r_lp[x]];
+                        }
+                    }
+                    for (int x = lane; x < c; x += 64) oth[r_cyc[x]] = r_hd[x];
+                    WFENCE();
+                    if (lane == 0) {
+                        const int mh = cur[k];
+                        oth[r_cyc[r_ep[mh]]] = rest[mh];
+                    }
+                    WFENCE();
+                    int *t = cur; cur = oth; oth = t;
+                }
+            }
+            // ------------------------------------------------------------------ single-root logic (ref :137-169)
+            int next = INT_MAX, done = 0;
+            if (err) {
+                done = 2;
+            } else if (root < 0) {
+                int nroot = 0;
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) {
+                    const int v = lane + 64 * q;
+                    const int hv = v < l ? cur[v] : -1;
+                    if (v < l) tree0[v] = hv;
+                    const unsigned long long bal = __ballot(v >= 1 && v < l && hv == 0);
+                    if (bal && next == INT_MAX) next = 64 * q + __builtin_ctzll(bal);
+                    nroot += __popcll(bal);
+                }
+                if (nroot == 1) {
+#pragma unroll
+                    for (int q = 0; q < NPL; ++q) {
+                        const int v = lane + 64 * q;
+                        if (v < l) hout[v] = cur[v];
+                    }
+                    if (lane == 0) a.status[b] = PHONLP_MST_OK;
+                    done = 1;
+                }
+            } else {
+                int finite = 1;
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) {
+                    const int i = lane + 64 * q;
+                    double v = 0.0;
+                    if (i < l) {
+                        const int j = cur[i];
+                        if (i == 0 || i == root) v = j == 0 ? 0.0 : NEG_INF_D;
+                        else if (j == 0 || j == i) v = NEG_INF_D;
+                        else v = (double)arc[(long)i * L + j];
+                        edge[i] = v;
+                    }
+                    if (__ballot(i < l && !(v > NEG_INF_D))) finite = 0;
+                }
+                WFENCE();
+                double score = NEG_INF_D;
+                if (finite) score = np_sum<4>(edge, l) + (double)arc[(long)root * L];
+                if (score > best_score) {  // strict: the first best candidate wins (ref :159)
+                    best_score = score;
+                    have_best = 1;
+#pragma unroll
+                    for (int q = 0; q < NPL; ++q) {
+                        const int v = lane + 64 * q;
+                        if (v < l) besttree[v] = cur[v];
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) {
+                    const int v = lane + 64 * q;
+                    const unsigned long long bal = __ballot(v < l && v > root && tree0[v] == 0);
+                    if (bal && next == INT_MAX) next = 64 * q + __builtin_ctzll(bal);
+                }
+            }
+            if (!done && next == INT_MAX) {  // candidates exhausted: emit the best tree (or report none)
+                if (have_best) {
+                    WFENCE();
+#pragma unroll
+                    for (int q = 0; q < NPL; ++q) {
+                        const int v = lane + 64 * q;
+                        if (v < l) hout[v] = besttree[v];
+                    }
+                    if (lane == 0) a.status[b] = PHONLP_MST_OK;
+                } else if (lane == 0) {
+                    a.status[b] = PHONLP_MST_NO_FINITE_TREE;
+                }
+                done = 1;
+            }
+            if (done == 2 && lane == 0) a.status[b] = 2;
+            if (lane == 0) { sc[WS_NEXT] = next; sc[WS_DONE] = done; }
+        }
+        __syncthreads();
+        if (sc[WS_DONE]) return;
+        root = sc[WS_NEXT];
+        __syncthreads();
+    }
+#undef SM
+}
+
+int launch_mst_wave(const MstArgs &a, hipStream_t stream) {
+    const WaveLayout w = wave_layout(a.L);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)mst_wave_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void *)mst_wave_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void *)mst_wave_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return fail(PHONLP_ERR_LAUNCH, "mst_one_root: cannot raise the dynamic LDS limit");
+        attr_set = true;
+    }
+    if (a.L <= 64) hipLaunchKernelGGL(mst_wave_kernel<1>, dim3(a.B), dim3(256), w.total, stream, a, w.stack_cap);
+    else if (a.L <= 128) hipLaunchKernelGGL(mst_wave_kernel<2>, dim3(a.B), dim3(256), w.total, stream, a, w.stack_cap);
+    else hipLaunchKernelGGL(mst_wave_kernel<4>, dim3(a.B), dim3(256), w.total, stream, a, w.stack_cap);
+    return check_launch("mst_wave_kernel");
+}
+
+}  // namespace phonlp
