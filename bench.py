@@ -98,7 +98,7 @@ def main():
     from phonlp_amd import HeadWeights, TaskHeads
     from phonlp_amd import synthetic as S
     from phonlp_amd.profile import KernelTimer
-    from phonlp_amd.sharding import eval_counts
+    from phonlp_amd import ops
 
     sd = S.make_state_dict(E, TE, H, U, O, T, seed=1234)
     heads = TaskHeads(HeadWeights.from_state_dict(sd, dev))
@@ -117,8 +117,8 @@ def main():
 
     def step():
         out = heads.annotate_batch(enc_dep, ld, enc_tag, lt)
-        counts.add_(eval_counts(out["pos"], out["ner"], out["heads"], out["rels"], gold_pos, gold_ner, gold_head,
-                                gold_rel, lt, ld, out["mst_status"]))
+        counts.add_(ops.eval_counts(out["pos"], out["ner"], out["heads"], out["rels"], gold_pos, gold_ner, gold_head,
+                                    gold_rel, lt, ld, out["mst_status"]))
         return out
 
     def fence():

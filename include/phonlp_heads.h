@@ -154,6 +154,25 @@ int phonlp_gather_labels(const int32_t *label_argmax, const int32_t *heads, cons
                          int32_t *rels, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * First-sub-word gather -- annotate_model.py:119-123 / :159-163 (one index_select per sentence in a Python
+ * loop): out[b, w, :] = enc[b, first_subword[b, w], :] for w < sentlens[b], zeros beyond (sentlens may be NULL:
+ * then every row is gathered, like the reference, whose padded rows are dropped later by pack()).
+ * enc [B,S,E] last hidden state, first_subword [B,L] int32 or int64 (index_is_int64), out [B,L,E].  E % 4 == 0.
+ */
+int phonlp_gather_first_subword(const float *enc, const void *first_subword, int index_is_int64,
+                                const int32_t *sentlens, int B, int S, int L, int E, float *out, void *stream);
+
+/* Eval counts -- what the reference's scorers accumulate per corpus (models/pos/scorer.py:29-36 POS accuracy;
+ * utils/conll18_ud_eval.py:531-532 UAS/LAS; tag-level NER agreement).  ADDS to counts[0..7] (int64, device):
+ * sentences, words, pos_correct, ner_correct, uas_correct, las_correct, mst_failures, 0.  Tagger tensors are
+ * [B,Lt], parser tensors [B,Ld] with column 0 = ROOT (skipped).  mst_status may be NULL.
+ */
+int phonlp_eval_counts(const int32_t *pos, const int32_t *ner, const int32_t *heads, const int32_t *rels,
+                       const int32_t *gold_pos, const int32_t *gold_ner, const int32_t *gold_head,
+                       const int32_t *gold_rel, const int32_t *lens_tag, const int32_t *lens_dep,
+                       const int32_t *mst_status, int B, int Lt, int Ld, int64_t *counts, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Per-kernel timing (no counterpart in the reference, which has no profiling: SURVEY.md section 5).
  * Between _begin and _end every kernel launch of the library is bracketed by a hipEvent pair recorded
  * on its launch stream (up to max_samples launches).  _end synchronises those events and copies the

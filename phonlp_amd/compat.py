@@ -106,8 +106,7 @@ def _encode(model, tokens, first_subword):
     dev = _dev()
     enc_dev = next(model.phobert.parameters()).device  # wherever the caller keeps the encoder
     emb = model.phobert(tokens.to(enc_dev))[2][-1]
-    idx = first_subword.to(enc_dev).unsqueeze(-1).expand(-1, -1, emb.size(-1))
-    return torch.gather(emb, 1, idx).float().to(dev).contiguous()
+    return ops.gather_first_subword(emb.float().to(dev).contiguous(), first_subword.to(dev).contiguous(), None)
 
 
 def _tagger_forward(self, tokens_phobert, words_phobert, sentlens):

@@ -209,3 +209,35 @@ def gather_labels(label_argmax: Tensor, heads: Tensor, sentlens: Tensor) -> Tens
     check(lib().phonlp_gather_labels(_p(label_argmax), _p(heads), _p(sentlens), B, L, _p(rels), _stream()),
           "phonlp_gather_labels")
     return rels
+
+
+@torch.library.custom_op("phonlp_amd::gather_first_subword", mutates_args=())
+def gather_first_subword(enc: Tensor, first_subword: Tensor, sentlens: Optional[Tensor]) -> Tensor:
+    """enc [B,S,E] (encoder last hidden state), first_subword [B,L] int32/int64 -> [B,L,E] word rows."""
+    _need(enc, torch.float32, "enc")
+    if first_subword.dtype not in (torch.int32, torch.int64) or not first_subword.is_cuda or not first_subword.is_contiguous():
+        raise ValueError("first_subword: expected a contiguous int32/int64 device tensor")
+    B, S, E = enc.shape
+    L = first_subword.shape[1]
+    out = torch.empty((B, L, E), dtype=torch.float32, device=enc.device)
+    check(lib().phonlp_gather_first_subword(_p(enc), _p(first_subword), int(first_subword.dtype == torch.int64),
+                                            _p(sentlens), B, S, L, E, _p(out), _stream()), "phonlp_gather_first_subword")
+    return out
+
+
+@torch.library.custom_op("phonlp_amd::eval_counts", mutates_args=())
+def eval_counts(pos: Tensor, ner: Tensor, heads: Tensor, rels: Tensor, gold_pos: Tensor, gold_ner: Tensor,
+                gold_head: Tensor, gold_rel: Tensor, lens_tag: Tensor, lens_dep: Tensor,
+                mst_status: Optional[Tensor]) -> Tensor:
+    """-> int64[8]: sentences, words, pos_correct, ner_correct, uas_correct, las_correct, mst_failures, 0."""
+    for n, t in (("pos", pos), ("ner", ner), ("heads", heads), ("rels", rels), ("gold_pos", gold_pos),
+                 ("gold_ner", gold_ner), ("gold_head", gold_head), ("gold_rel", gold_rel), ("lens_tag", lens_tag),
+                 ("lens_dep", lens_dep)):
+        _need(t, torch.int32, n)
+    B, Lt = pos.shape
+    Ld = heads.shape[1]
+    counts = torch.zeros(8, dtype=torch.int64, device=pos.device)
+    check(lib().phonlp_eval_counts(_p(pos), _p(ner), _p(heads), _p(rels), _p(gold_pos), _p(gold_ner), _p(gold_head),
+                                   _p(gold_rel), _p(lens_tag), _p(lens_dep), _p(mst_status), B, Lt, Ld, _p(counts),
+                                   _stream()), "phonlp_eval_counts")
+    return counts

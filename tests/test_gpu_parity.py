@@ -348,3 +348,38 @@ def test_headline_batch_properties(dev):
     rel_want = np.take_along_axis(dep["label_argmax"].cpu().numpy(), h[:, :, None].astype(np.int64), 2)[:, :, 0]
     rel_want[:, 0] = 0
     assert np.array_equal(big["rels"].cpu().numpy(), rel_want)
+
+
+# ------------------------------------------------------------------------------------------ glue kernels (section 8f)
+@pytest.mark.parametrize("B,S,L,E,idx_dtype", [(5, 40, 19, 32, torch.int64), (64, 200, 128, 768, torch.int32)])
+def test_gather_first_subword(dev, B, S, L, E, idx_dtype):
+    from phonlp_amd import ops
+    g = torch.Generator().manual_seed(B + S)
+    enc = torch.randn(B, S, E, generator=g)
+    idx = torch.randint(0, S, (B, L), generator=g).to(idx_dtype)
+    lens = torch.randint(1, L + 1, (B,), generator=g).to(torch.int32)
+    want = torch.stack([enc[b].index_select(0, idx[b].long()) for b in range(B)])  # ref annotate_model.py:120-123
+    got = ops.gather_first_subword(enc.to(dev), idx.to(dev), None)
+    assert torch.equal(got.cpu(), want)  # a copy: bit-exact
+    got = ops.gather_first_subword(enc.to(dev), idx.to(dev), lens.to(dev))
+    mask = (torch.arange(L).unsqueeze(0) < lens.unsqueeze(1)).unsqueeze(-1)
+    assert torch.equal(got.cpu(), want * mask)
+
+
+def test_eval_counts_vs_python(dev):
+    from phonlp_amd import ops
+    from phonlp_amd.sharding import eval_counts
+    g = torch.Generator().manual_seed(3)
+    B, Ld = 37, 50
+    Lt = Ld - 1
+    ri = lambda hi, shape: torch.randint(0, hi, shape, generator=g, dtype=torch.int32)
+    pos, ner, gpos, gner = ri(4, (B, Lt)), ri(3, (B, Lt)), ri(4, (B, Lt)), ri(3, (B, Lt))
+    heads, rels, ghead, grel = ri(5, (B, Ld)), ri(3, (B, Ld)), ri(5, (B, Ld)), ri(3, (B, Ld))
+    lens_dep = torch.randint(2, Ld + 1, (B,), generator=g, dtype=torch.int32)
+    lens_tag = lens_dep - 1
+    status = (torch.rand(B, generator=g) < 0.1).to(torch.int32)
+    want = eval_counts(pos, ner, heads, rels, gpos, gner, ghead, grel, lens_tag, lens_dep, status)
+    d = lambda t: t.to(dev)
+    got = ops.eval_counts(d(pos), d(ner), d(heads), d(rels), d(gpos), d(gner), d(ghead), d(grel), d(lens_tag),
+                          d(lens_dep), d(status))
+    assert got.cpu().tolist() == want.tolist()
