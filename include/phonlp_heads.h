@@ -54,6 +54,14 @@ const char *phonlp_last_error(void);
  * rows are written as exact zeros (pad_packed_sequence semantics, annotate_model.py:150,187).
  * Requires K % 4 == 0, ldx % 4 == 0, ldw % 4 == 0, 16-byte aligned X and W.
  */
+/* GEMM engine used by every matrix kernel of the library (process-wide; default 1, or $PHONLP_GEMM_ENGINE):
+ *   0  v_mfma_f32_32x32x2_f32: exact fp32 multiply-add chain;
+ *   1  "bf16x6": each fp32 operand split exactly into three bf16 pieces in registers, six
+ *      v_mfma_f32_32x32x16_bf16 products, fp32 accumulate -- fp32-equivalent (dropped terms <= 3*2^-24 |a||b|),
+ *      about twice as fast.  Same memory layouts, same entry points. */
+int phonlp_set_gemm_engine(int engine);
+int phonlp_get_gemm_engine(void);
+
 int phonlp_linear(const float *X, int ldx, const float *W, int ldw, const float *bias, float *Y, int ldy,
                   int M, int N, int K, int relu, const int32_t *sentlens, int L, void *stream);
 

@@ -13,6 +13,8 @@ SIGNATURES = {
     "phonlp_kp": (_i, [_i]),
     "phonlp_version": (_i, []),
     "phonlp_last_error": (ctypes.c_char_p, []),
+    "phonlp_set_gemm_engine": (_i, [_i]),
+    "phonlp_get_gemm_engine": (_i, []),
     "phonlp_linear": (_i, [_p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p, _i, _p]),
     "phonlp_pack_scorer_linear": (_i, [_p, _p, _p, _p, _i, _i, _p, _p, _p]),
     "phonlp_pack_bilinear": (_i, [_p, _i, _i, _p, _p]),

@@ -11,6 +11,7 @@
 
 namespace phonlp {
 
+int gemm_engine();
 int launch_linear(const char *tag, const float *X, long ldx, const float *W, long ldw, const float *bias, float *Y, long ldy, int M,
                   int N, int K, int relu, const int32_t *sentlens, int L, hipStream_t stream);
 
@@ -42,6 +43,7 @@ __device__ __forceinline__ float softplus(float x) { return x > 20.f ? x : log1p
 
 // One block = 32 dependents (rows i) of one sentence against all L heads.  4 waves; per 128-wide
 // column group wave w owns columns [32w, 32w+32).
+template <int ENG>
 __global__ __launch_bounds__(256) void arc_kernel(ArcArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *As = smem;
@@ -81,9 +83,9 @@ __global__ __launch_bounds__(256) void arc_kernel(ArcArgs a) {
             }
             const float *Bw = Bs + wave * 32 * PITCH;
             const int depth = slab_depth((it - s * nk) * BK, KP);
-            if (s == 0) mma_slab<1, 1>(As, Bw, lane, acc0, depth);
-            else if (s == 1) mma_slab<1, 1>(As, Bw, lane, acc1, depth);
-            else mma_slab<1, 1>(As, Bw, lane, acc2, depth);
+            if (s == 0) mma_slab<1, 1, ENG>(As, Bw, lane, acc0, depth);
+            else if (s == 1) mma_slab<1, 1, ENG>(As, Bw, lane, acc1, depth);
+            else mma_slab<1, 1, ENG>(As, Bw, lane, acc2, depth);
             __syncthreads();
             if (it + 1 < total) {
                 slab_store(ra, As, tid);
@@ -157,6 +159,7 @@ struct LabelArgs {
 // 64 x 32 sub-tile.  The K loop runs over (o, k): after the last slab of relation o the
 // accumulators are folded into a running (max, arg-max) pair and cleared.  Strict '>' keeps the
 // lowest o on ties (CPU torch.max / np.argmax semantics).
+template <int ENG>
 __global__ __launch_bounds__(512) void label_kernel(LabelArgs a) {
     constexpr int THREADS = 512;
     __shared__ __attribute__((aligned(16))) float lds[256 * PITCH];
@@ -201,7 +204,7 @@ __global__ __launch_bounds__(512) void label_kernel(LabelArgs a) {
             slab_load(ra, Tb + (long)o2 * KP, a.ldT, iv, k2 * BK, KP, tid);
             slab_load(rb, Xb, a.ldx, jv, k2 * BK, KP, tid);
         }
-        mma_slab<2, 1>(As + wm * 64 * PITCH, Bs + wn * 32 * PITCH, lane, acc, slab_depth(kk * BK, KP));
+        mma_slab<2, 1, ENG>(As + wm * 64 * PITCH, Bs + wn * 32 * PITCH, lane, acc, slab_depth(kk * BK, KP));
         if (kk == nk - 1) {
             const int col = j0 + wn * 32 + (lane & 31);
 #pragma unroll
@@ -288,13 +291,16 @@ extern "C" int phonlp_deep_biaffine_arc(const float *hidden, int D, int B, int L
     const size_t lds = (size_t)(160 * PITCH + 32 * a.LP) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)arc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
-            hipSuccess)
+        if (hipFuncSetAttribute((const void *)arc_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+                hipSuccess ||
+            hipFuncSetAttribute((const void *)arc_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+                hipSuccess)
             return fail(PHONLP_ERR_LAUNCH, "deep_biaffine_arc: cannot raise the dynamic LDS limit");
         attr_set = true;
     }
     ProfScope ps("arc_stage_b", st);
-    hipLaunchKernelGGL(arc_kernel, dim3(ceil_div(L, 32), B), dim3(256), lds, st, a);
+    if (gemm_engine()) hipLaunchKernelGGL(arc_kernel<1>, dim3(ceil_div(L, 32), B), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL(arc_kernel<0>, dim3(ceil_div(L, 32), B), dim3(256), lds, st, a);
     return check_launch("arc_kernel");
 }
 
@@ -320,7 +326,8 @@ extern "C" int phonlp_deep_biaffine_label(const float *hidden, int D, int B, int
     if (rc) return rc;
     LabelArgs a{T, XF + KP, label_argmax, scores_opt, (long)O * KP, 2L * KP, B, L, O, KP, ceil_div(L, 128)};
     ProfScope ps("label_stage_b", st);
-    hipLaunchKernelGGL(label_kernel, dim3(B * a.tiles * a.tiles), dim3(512), 0, st, a);
+    if (gemm_engine()) hipLaunchKernelGGL(label_kernel<1>, dim3(B * a.tiles * a.tiles), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL(label_kernel<0>, dim3(B * a.tiles * a.tiles), dim3(512), 0, st, a);
     return check_launch("label_kernel");
 }
 

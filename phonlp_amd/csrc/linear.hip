@@ -19,6 +19,71 @@ struct LinearArgs {
     int num_m, num_n;
 };
 
+// Epilogue shared by the dense-layer kernels: the wave's accumulators are transposed through a per-wave LDS
+// patch (32 rows x (TN*32 + 4) floats at lds + wave * 32 * EP; the caller guarantees WM*WN such patches fit and
+// that no wave still reads the slab images they alias) so that every global store is a 16-byte-per-lane row
+// segment; bias / ReLU / padding mask fused.
+template <int TM, int TN, int WM, int WN>
+__device__ __forceinline__ void linear_epilogue(f32x16 (&acc)[TM][TN], float *lds, const LinearArgs &a, int m0, int n0,
+                                                int wm, int wn, int lane, int wave) {
+            constexpr int WCOLS = TN * 32, EP = WCOLS + 4;
+            float *ep = lds + wave * 32 * EP;
+            constexpr int LPR = WCOLS / 4;   // lanes per row
+            constexpr int RPI = 64 / LPR;    // rows per wave-instruction
+            const int c4 = (lane % LPR) * 4;
+            const int col = n0 + wn * WCOLS + c4;
+            const int rsub = lane / LPR;
+            const bool vec_ok = ((a.ldy & 3) == 0) && (((uintptr_t)a.Y & 15) == 0) && (col + 3 < a.N);
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.bias) {
+                if (col < a.N) bv.x = a.bias[col];
+                if (col + 1 < a.N) bv.y = a.bias[col + 1];
+                if (col + 2 < a.N) bv.z = a.bias[col + 2];
+                if (col + 3 < a.N) bv.w = a.bias[col + 3];
+            }
+            unsigned live[TM];
+    #pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                live[i] = 0xFFFFFFFFu;
+                if (a.sentlens) {
+                    live[i] = 0;
+    #pragma unroll
+                    for (int it = 0; it < 32 / RPI; ++it) {
+                        const int row = m0 + (wm * TM + i) * 32 + it * RPI + rsub;
+                        if (row < a.M && (row % a.L) < a.sentlens[row / a.L]) live[i] |= 1u << it;
+                    }
+                }
+            }
+    #pragma unroll
+            for (int i = 0; i < TM; ++i) {
+    #pragma unroll
+                for (int j = 0; j < TN; ++j)
+    #pragma unroll
+                    for (int r = 0; r < 16; ++r) ep[acc_row(r, lane) * EP + j * 32 + (lane & 31)] = acc[i][j][r];
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    #pragma unroll
+                for (int it = 0; it < 32 / RPI; ++it) {
+                    const int lrow = it * RPI + rsub;
+                    const int row = m0 + (wm * TM + i) * 32 + lrow;
+                    float4 v = *reinterpret_cast<const float4 *>(ep + lrow * EP + c4);
+                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                    if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    if (!((live[i] >> it) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (row >= a.M || col >= a.N) continue;
+                    float *y = a.Y + (long)row * a.ldy + col;
+                    if (vec_ok) {
+                        *reinterpret_cast<float4 *>(y) = v;
+                    } else {
+                        y[0] = v.x;
+                        if (col + 1 < a.N) y[1] = v.y;
+                        if (col + 2 < a.N) y[2] = v.z;
+                        if (col + 3 < a.N) y[3] = v.w;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
+}
+
 // BM x BN block tile, WM x WN waves, each wave a (BM/WM) x (BN/WN) sub-tile.  TAG only names the
 // instantiation (TAG 1 = bilinear stage A of the label scorer, so profilers list it on its own row).
 //
@@ -38,12 +103,13 @@ struct LinearArgs {
 // Tile order: block b belongs to XCD group x = b % 8 (blocks b, b+8, ... share an L2), local index
 // j = b / 8; in round i it takes tile (i*8 + x)*Gx + j of a sequence that walks 8-tile-tall column-major
 // groups, so the Gx blocks of one XCD work on one compact patch of tiles sharing A and B panels.
-template <int BM, int BN, int WM, int WN, int TAG>
+template <int BM, int BN, int WM, int WN, int TAG, int ENG>
 __global__ __launch_bounds__(WM *WN * 64, 2) void linear_kernel(LinearArgs a) {
     constexpr int THREADS = WM * WN * 64;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int BUF = (BM + BN) * PITCH;
     __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
+    static_assert(WM * WN * 32 * (TN * 32 + 4) <= 2 * BUF, "epilogue patch must fit the slab buffers");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -104,7 +170,7 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void linear_kernel(LinearArgs a) {
             slab_load(ra, Xt, a.ldx, mv, k1, a.K, tid);
             slab_load(rb, Wt, a.ldw, nv, k1, a.K, tid);
             const float *As = lds + cur * BUF, *Bs = As + BM * PITCH;
-            mma_slab_d<TM, TN, 32>(As + wm * TM * 32 * PITCH, Bs + wn * TN * 32 * PITCH, lane, acc);
+            mma_slab_d<TM, TN, 32, ENG>(As + wm * TM * 32 * PITCH, Bs + wn * TN * 32 * PITCH, lane, acc);
             float *An = lds + (cur ^ 1) * BUF;
             slab_store(ra, An, tid);
             slab_store(rb, An + BM * PITCH, tid);
@@ -120,69 +186,12 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void linear_kernel(LinearArgs a) {
         }
         {
             const float *As = lds + cur * BUF, *Bs = As + BM * PITCH;
-            mma_slab<TM, TN>(As + wm * TM * 32 * PITCH, Bs + wn * TN * 32 * PITCH, lane, acc,
+            mma_slab<TM, TN, ENG>(As + wm * TM * 32 * PITCH, Bs + wn * TN * 32 * PITCH, lane, acc,
                              slab_depth((nslab - 1) * BK, a.K));
             lds_barrier();  // not __syncthreads(): the next tile's prefetch must stay in flight
         }
 
-        // ---- epilogue
-        constexpr int WCOLS = TN * 32, EP = WCOLS + 4;
-        static_assert(WM * WN * 32 * EP <= 2 * BUF, "epilogue patch must fit the slab buffers");
-        float *ep = lds + wave * 32 * EP;
-        constexpr int LPR = WCOLS / 4;   // lanes per row
-        constexpr int RPI = 64 / LPR;    // rows per wave-instruction
-        const int c4 = (lane % LPR) * 4;
-        const int col = n0 + wn * WCOLS + c4;
-        const int rsub = lane / LPR;
-        const bool vec_ok = ((a.ldy & 3) == 0) && (((uintptr_t)a.Y & 15) == 0) && (col + 3 < a.N);
-        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a.bias) {
-            if (col < a.N) bv.x = a.bias[col];
-            if (col + 1 < a.N) bv.y = a.bias[col + 1];
-            if (col + 2 < a.N) bv.z = a.bias[col + 2];
-            if (col + 3 < a.N) bv.w = a.bias[col + 3];
-        }
-        unsigned live[TM];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            live[i] = 0xFFFFFFFFu;
-            if (a.sentlens) {
-                live[i] = 0;
-#pragma unroll
-                for (int it = 0; it < 32 / RPI; ++it) {
-                    const int row = m0 + (wm * TM + i) * 32 + it * RPI + rsub;
-                    if (row < a.M && (row % a.L) < a.sentlens[row / a.L]) live[i] |= 1u << it;
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) ep[acc_row(r, lane) * EP + j * 32 + (lane & 31)] = acc[i][j][r];
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#pragma unroll
-            for (int it = 0; it < 32 / RPI; ++it) {
-                const int lrow = it * RPI + rsub;
-                const int row = m0 + (wm * TM + i) * 32 + lrow;
-                float4 v = *reinterpret_cast<const float4 *>(ep + lrow * EP + c4);
-                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-                if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                if (!((live[i] >> it) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (row >= a.M || col >= a.N) continue;
-                float *y = a.Y + (long)row * a.ldy + col;
-                if (vec_ok) {
-                    *reinterpret_cast<float4 *>(y) = v;
-                } else {
-                    y[0] = v.x;
-                    if (col + 1 < a.N) y[1] = v.y;
-                    if (col + 2 < a.N) y[2] = v.z;
-                    if (col + 3 < a.N) y[3] = v.w;
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        }
+        linear_epilogue<TM, TN, WM, WN>(acc, lds, a, m0, n0, wm, wn, lane, wave);
         lds_barrier();  // the patches alias the slab buffers the next tile is about to fill; the tile's global
                         // stores are NOT waited for (a full barrier would expose their write latency per tile)
         have = have1;
@@ -191,6 +200,140 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void linear_kernel(LinearArgs a) {
         ++round;
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Engine 1 dense layer: fp32-equivalent product on the bf16 matrix pipe, operands split ONCE PER BLOCK while
+// they are staged.  The fp32 slab a thread fetched (global_load_dwordx4, as in engine 0) is split exactly into
+// three bf16 pieces (mma_f32.h: hi / mid / lo by truncation) and written to three bf16 LDS planes per operand;
+// the MFMA loop is then nothing but ds_read_b128 + v_mfma_f32_32x32x16_bf16 (12 reads feed 24 MFMAs per k16
+// step of a 64x64 wave tile -- twice the MFMA work per LDS byte of a plain bf16 GEMM).  Splitting at staging
+// costs ~5 VALU ops per element once per 128-wide tile, instead of once per wave per fragment use.
+//
+// LDS image (one buffer, 48 KB, so two or three blocks share a CU and cover each other's barriers):
+//   plane p of A at p*BM*64 bytes, of B at (3*BM + p*BN)*64; a plane row is the slab's 32 bf16 (64 bytes) as
+//   four 16-byte chunks, chunk c of row R stored at chunk slot c ^ ((R>>2)&3): the 16 lanes of a
+//   ds_read_b128 group (16 rows, one chunk index) then cover all 64 banks, and the 16 lanes of a
+//   ds_write_b64 group (two whole rows) cover the 32 banks of a store exactly once.
+// Loop per slab: split+store slab k | barrier | issue global loads of slab k+1 | MFMAs on slab k | barrier.
+template <int TAG>
+__global__ __launch_bounds__(256, 2) void linear_split_kernel(LinearArgs a) {
+    constexpr int BM = 128, BN = 128, WM = 2, WN = 2, TM = 2, TN = 2, THREADS = 256;
+    constexpr int PLANE_A = BM * 64, PLANE_B = BN * 64;        // bytes
+    constexpr int LDS_BYTES = 3 * PLANE_A + 3 * PLANE_B;       // 49152
+    static_assert(WM * WN * 32 * (TN * 32 + 4) * 4 <= LDS_BYTES, "epilogue patch must fit the slab image");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int ntiles = a.num_m * a.num_n;
+    const int nslab = (a.K + BK - 1) / BK;
+    int m0, n0;
+    {   // one tile per block; blocks b, b+8, ... (one XCD) take a contiguous chunk of the 8-tall column-major walk
+        const int xg = blockIdx.x & 7, jl = blockIdx.x >> 3;
+        const int q = ntiles >> 3, r = ntiles & 7;
+        const int t = (xg < r ? xg * (q + 1) : r * (q + 1) + (xg - r) * q) + jl;
+        constexpr int GM = 8;
+        const int per_group = GM * a.num_n;
+        const int g = t / per_group;
+        const int first_m = g * GM;
+        const int gsz = (a.num_m - first_m) < GM ? (a.num_m - first_m) : GM;
+        const int in = t - g * per_group;
+        m0 = (first_m + in % gsz) * BM;
+        n0 = (in / gsz) * BN;
+    }
+    const float *Xt = a.X + (long)m0 * a.ldx;
+    const float *Wt = a.W + (long)n0 * a.ldw;
+    const int mv = a.M - m0, nv = a.N - n0;
+
+    // staging: thread -> (row = idx>>3, float4 column (idx&7)); its 4 bf16 per plane are half of chunk (idx&7)>>1
+    auto stage = [&](const float4 (&v)[4], unsigned char *plane0, int plane_bytes) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = tid + q * THREADS;
+            const int row = idx >> 3, c8 = idx & 7;
+            uint2 h, m, l;
+            split3_f4(v[q], h, m, l);
+            unsigned char *p = plane0 + row * 64 + ((((c8 >> 1) ^ (row >> 2)) & 3) << 4) + ((c8 & 1) << 3);
+            *reinterpret_cast<uint2 *>(p) = h;
+            *reinterpret_cast<uint2 *>(p + plane_bytes) = m;
+            *reinterpret_cast<uint2 *>(p + 2 * plane_bytes) = l;
+        }
+    };
+    // fragment reads: lane (r = lane&31, h = lane>>5) takes k = kb + 8h .. +7 of row r: chunk (kb>>3) + h
+    const int r = lane & 31, hh = lane >> 5;
+    const int sw = (r >> 2) & 3;
+    const unsigned char *Ab = lds + (wm * 64 + r) * 64;
+    const unsigned char *Bb = lds + 3 * PLANE_A + (wn * 64 + r) * 64;
+    const int off0 = ((hh ^ sw) & 3) << 4;  // k16 step 0; step 1 is chunk (2 + h): off0 ^ 32
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    auto k16 = [&](int off) {
+        u32x4 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bh[j] = *reinterpret_cast<const u32x4 *>(Bb + j * 32 * 64 + off);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) al[i] = *reinterpret_cast<const u32x4 *>(Ab + 2 * PLANE_A + i * 32 * 64 + off);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) ah[i] = *reinterpret_cast<const u32x4 *>(Ab + i * 32 * 64 + off);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bl[j] = *reinterpret_cast<const u32x4 *>(Bb + 2 * PLANE_B + j * 32 * 64 + off);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) am[i] = *reinterpret_cast<const u32x4 *>(Ab + PLANE_A + i * 32 * 64 + off);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bm[j] = *reinterpret_cast<const u32x4 *>(Bb + PLANE_B + j * 32 * 64 + off);
+#define PHONLP_X6_ROUND(AA, BB)                                               \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                            \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] = PHONLP_BF16_MFMA(AA[i], BB[j], acc[i][j]);
+        PHONLP_X6_ROUND(al, bh)
+        PHONLP_X6_ROUND(ah, bl)
+        PHONLP_X6_ROUND(am, bm)
+        PHONLP_X6_ROUND(am, bh)
+        PHONLP_X6_ROUND(ah, bm)
+        PHONLP_X6_ROUND(ah, bh)
+#undef PHONLP_X6_ROUND
+    };
+
+    Slab<BM, THREADS> ra;
+    Slab<BN, THREADS> rb;
+    slab_load(ra, Xt, a.ldx, mv, 0, a.K, tid);
+    slab_load(rb, Wt, a.ldw, nv, 0, a.K, tid);
+    for (int sidx = 0; sidx < nslab - 1; ++sidx) {
+        stage(ra.v, lds, PLANE_A);
+        stage(rb.v, lds + 3 * PLANE_A, PLANE_B);
+        lds_barrier();
+        const int k1 = (sidx + 1) * BK;
+        slab_load(ra, Xt, a.ldx, mv, k1, a.K, tid);
+        slab_load(rb, Wt, a.ldw, nv, k1, a.K, tid);
+        k16(off0);
+        k16(off0 ^ 32);
+        lds_barrier();
+    }
+    stage(ra.v, lds, PLANE_A);
+    stage(rb.v, lds + 3 * PLANE_A, PLANE_B);
+    lds_barrier();
+    k16(off0);
+    if (a.K - (nslab - 1) * BK > 16) k16(off0 ^ 32);
+    lds_barrier();
+    linear_epilogue<TM, TN, WM, WN>(acc, reinterpret_cast<float *>(lds), a, m0, n0, wm, wn, lane, wave);
+}
+
+// GEMM engine shared by every MFMA kernel of the library: 0 = f32 MFMA (exact fp32 chain), 1 = bf16x6 (default).
+static int g_engine = -1;
+int gemm_engine() {
+    if (g_engine < 0) {
+        const char *e = getenv("PHONLP_GEMM_ENGINE");
+        g_engine = e ? (atoi(e) != 0) : 1;
+    }
+    return g_engine;
+}
+void set_gemm_engine(int e) { g_engine = e != 0; }
 
 // Grid size.  One block per tile by default.  PHONLP_GEMM_PERSISTENT=1 selects a persistent grid of two blocks
 // per CU walking strided tiles (+3 % when the GEMM has the chip to itself, but its static partition stalls
@@ -211,15 +354,26 @@ int launch_linear(const char *tag, const float *X, long ldx, const float *W, lon
     const bool stage_a = tag && !strcmp(tag, "linear:label_stage_a");
     ProfScope ps(tag, stream);
     a.num_m = ceil_div(M, 128);
+    const int eng = gemm_engine();
     if (N <= 64) {
         a.num_n = ceil_div(N, 32);
-        hipLaunchKernelGGL((linear_kernel<128, 32, 4, 1, 0>), dim3(persistent_grid(a.num_m * a.num_n)), dim3(256), 0,
-                           stream, a);
+        const dim3 g(persistent_grid(a.num_m * a.num_n));
+        if (eng) hipLaunchKernelGGL((linear_kernel<128, 32, 4, 1, 0, 1>), g, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((linear_kernel<128, 32, 4, 1, 0, 0>), g, dim3(256), 0, stream, a);
     } else {
         a.num_n = ceil_div(N, 128);
         const dim3 g(persistent_grid(a.num_m * a.num_n));
-        if (stage_a) hipLaunchKernelGGL((linear_kernel<128, 128, 2, 2, 1>), g, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((linear_kernel<128, 128, 2, 2, 0>), g, dim3(256), 0, stream, a);
+        static const bool in_regs = getenv("PHONLP_X6_IN_REGS") != nullptr;  // A/B switch: split per fragment use
+        const dim3 g1(a.num_m * a.num_n);
+        if (stage_a) {
+            if (eng && !in_regs) hipLaunchKernelGGL((linear_split_kernel<1>), g1, dim3(256), 0, stream, a);
+            else if (eng) hipLaunchKernelGGL((linear_kernel<128, 128, 2, 2, 1, 1>), g, dim3(256), 0, stream, a);
+            else hipLaunchKernelGGL((linear_kernel<128, 128, 2, 2, 1, 0>), g, dim3(256), 0, stream, a);
+        } else {
+            if (eng && !in_regs) hipLaunchKernelGGL((linear_split_kernel<0>), g1, dim3(256), 0, stream, a);
+            else if (eng) hipLaunchKernelGGL((linear_kernel<128, 128, 2, 2, 0, 1>), g, dim3(256), 0, stream, a);
+            else hipLaunchKernelGGL((linear_kernel<128, 128, 2, 2, 0, 0>), g, dim3(256), 0, stream, a);
+        }
     }
     return check_launch("linear_kernel");
 }
@@ -256,6 +410,13 @@ __global__ void pack_bilinear_kernel(const float *weight, int H, int O, int KP, 
 }  // namespace phonlp
 
 using namespace phonlp;
+
+extern "C" int phonlp_set_gemm_engine(int engine) {
+    if (engine != 0 && engine != 1) return fail(PHONLP_ERR_SHAPE, "set_gemm_engine: 0 (f32 MFMA) or 1 (bf16x6)");
+    set_gemm_engine(engine);
+    return PHONLP_OK;
+}
+extern "C" int phonlp_get_gemm_engine(void) { return gemm_engine(); }
 
 extern "C" int phonlp_linear(const float *X, int ldx, const float *W, int ldw, const float *bias, float *Y, int ldy,
                              int M, int N, int K, int relu, const int32_t *sentlens, int L, void *stream) {

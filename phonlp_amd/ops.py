@@ -35,6 +35,15 @@ def _ws(nbytes: int, device) -> Tensor:
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
 
+def set_gemm_engine(engine: int) -> None:
+    """0 = f32 MFMA (exact fp32 chain), 1 = fp32-equivalent 3-way bf16 split on the bf16 MFMA pipe.  Process-wide."""
+    check(lib().phonlp_set_gemm_engine(int(engine)), "set_gemm_engine")
+
+
+def get_gemm_engine() -> int:
+    return int(lib().phonlp_get_gemm_engine())
+
+
 def kp(H: int) -> int:
     return lib().phonlp_kp(H)
 

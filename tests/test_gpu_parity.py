@@ -23,6 +23,16 @@ def dev():
     return torch.device("cuda:0")
 
 
+@pytest.fixture(params=[0, 1], ids=["f32mfma", "bf16x6"])
+def engine(request, dev):
+    """Runs a GEMM-bearing test once per matrix engine of the library (include/phonlp_heads.h)."""
+    from phonlp_amd import ops
+    before = ops.get_gemm_engine()
+    ops.set_gemm_engine(request.param)
+    yield request.param
+    ops.set_gemm_engine(before)
+
+
 def _params(z, prefix="p_"):
     return {k[len(prefix):]: torch.from_numpy(z[k]) for k in z.files if k.startswith(prefix)}
 
@@ -39,7 +49,7 @@ def _close(got, want, rtol=2e-4, atol=2e-5):
     (300, 70, 868, True, False), (129, 9, 868, True, True), (64, 416, 416, False, False),
     (1000, 868, 868, False, True), (257, 24, 400, False, True), (128, 128, 32, True, False), (5, 3, 4, False, False),
 ])
-def test_linear_vs_torch_fp32(dev, M, N, K, relu, masked):
+def test_linear_vs_torch_fp32(dev, engine, M, N, K, relu, masked):
     from phonlp_amd import ops
     g = torch.Generator().manual_seed(M * 7 + N)
     x = torch.randn(M, K, generator=g)
@@ -56,6 +66,31 @@ def test_linear_vs_torch_fp32(dev, M, N, K, relu, masked):
         ref = ref * ((rows % L) < lens[rows // L].long()).unsqueeze(1)
     got = ops.linear(x.to(dev), w.to(dev), b.to(dev), relu, lens.to(dev) if masked else None, L if masked else 0)
     torch.testing.assert_close(got.cpu(), ref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 640, 401), (256, 868, 868), (384, 256, 4096)])
+def test_engines_against_fp64(dev, M, N, K):
+    """Both matrix engines are fp32-grade: error against an fp64 product, in units of sum_k |a||b| (the scale an
+    fp32 dot product's rounding error lives on), stays below 1e-6, and the bf16-split engine is no worse than
+    the f32 MFMA chain.  Rows carry widely different magnitudes (exp(2*N(0,1))) to exercise the split."""
+    from phonlp_amd import ops
+    g = torch.Generator().manual_seed(K)
+    Kp = (K + 3) // 4 * 4
+    x = torch.zeros(M, Kp); x[:, :K] = torch.randn(M, K, generator=g) * torch.exp(2 * torch.randn(M, 1, generator=g))
+    w = torch.zeros(N, Kp); w[:, :K] = torch.randn(N, K, generator=g) * torch.exp(torch.randn(N, 1, generator=g))
+    ref = x.double() @ w.double().t()
+    scale = x.double().abs() @ w.double().abs().t()
+    errs = []
+    before = ops.get_gemm_engine()
+    try:
+        for e in (0, 1):
+            ops.set_gemm_engine(e)
+            y = ops.linear(x.to(dev), w.to(dev), None, False, None, 0).cpu().double()
+            errs.append(((y - ref).abs() / scale).max().item())
+    finally:
+        ops.set_gemm_engine(before)
+    assert errs[0] < 1e-6 and errs[1] < 1e-6, errs
+    assert errs[1] <= 1.5 * errs[0] + 1e-8, errs
 
 
 # ------------------------------------------------------------------------------------------ Viterbi
@@ -197,7 +232,7 @@ def test_mst_root_only_sentence_reports_no_tree(dev):
 
 
 # ------------------------------------------------------------------------------------------ biaffine fixtures
-def test_deep_biaffine_golden(dev, golden):
+def test_deep_biaffine_golden(dev, engine, golden):
     """DeepBiaffineScorer fixtures (reference output, incl. the flat-reshape quirk and the ignored bias)."""
     from phonlp_amd import ops
     z = golden("biaffine.npz")
@@ -221,7 +256,7 @@ def test_deep_biaffine_golden(dev, golden):
 
 # ------------------------------------------------------------------------------------------ whole head path
 @pytest.mark.parametrize("name", ["joint_small.npz", "joint_zero_init.npz"])
-def test_joint_fixture_end_to_end(dev, golden, name):
+def test_joint_fixture_end_to_end(dev, engine, golden, name):
     """The reference's own dep_forward / tagger_forward / decoders on a ragged batch (fixture made by running
     annotate_model.JointModel) against the HIP path fed the same encoder rows."""
     from phonlp_amd import HeadWeights, TaskHeads
@@ -281,7 +316,7 @@ def _near_tie_ok(got_idx, want_idx, scores, tol):
 
 
 @pytest.mark.parametrize("B,L,ragged", [(32, 64, False), (24, 128, True), (3, 200, True)])
-def test_synthetic_heads_vs_oracle(dev, B, L, ragged):
+def test_synthetic_heads_vs_oracle(dev, engine, B, L, ragged):
     """BASELINE config 2 (B=32, L=64) and ragged / long variants with the 768/400/33/9 head sizes."""
     from phonlp_amd import HeadWeights, TaskHeads
     from phonlp_amd import synthetic as S
@@ -317,7 +352,7 @@ def test_synthetic_heads_vs_oracle(dev, B, L, ragged):
     assert (h.cpu().numpy() != oh).mean() <= 0.002
 
 
-def test_headline_batch_properties(dev):
+def test_headline_batch_properties(dev, engine):
     """B=256, L=128 (BASELINE config 3): sentences are independent, so any sub-batch must reproduce the big
     batch bit-for-bit; decoded trees must be single-rooted and acyclic; decoders match the C oracle."""
     from phonlp_amd import HeadWeights, TaskHeads
