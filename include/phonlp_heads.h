@@ -129,6 +129,20 @@ int phonlp_deep_biaffine_label(const float *hidden, int D, int B, int L, int H, 
                                const float *W12, const float *b12, const float *Wbt,
                                int32_t *label_argmax, float *scores_opt, void *ws, size_t ws_bytes, void *stream);
 
+/* The same scorer cut at the MST, for annotate(): the reference computes the whole label tensor
+ * (annotate_model.py:190,215) but reads it only at j = heads[b,i] (annotate_model.py:263-266:
+ * `deprel_seqs[i][j+1][h]` after the MST).  phonlp_label_project runs the scorer's two GEMMs into caller
+ * buffers -- XF [B*L, 2*KP] = (relu(W1 x + b1) | 1 | 0.. , relu(W2 x + b2) | 1 | 0..), T [B*L, O*KP] with
+ * T[b,i,o,:] = h1[b,i]^T W_o -- and can run beside the MST; phonlp_label_at_heads then gives
+ *   rels[b,i] = argmax_o T[b,i,o,:] . h2[b,heads[b,i],:]   for 1 <= i < sentlens[b], 0 elsewhere
+ * (lowest o on ties), i.e. phonlp_gather_labels(phonlp_deep_biaffine_label(...)) without the L x L x O
+ * contraction.  best_opt: NULL or [B*L] receiving the winning score.
+ */
+int phonlp_label_project(const float *hidden, int D, int B, int L, int H, int O,
+                         const float *W12, const float *b12, const float *Wbt, float *XF, float *T, void *stream);
+int phonlp_label_at_heads(const float *T, const float *XF, const int32_t *heads, const int32_t *sentlens,
+                          int B, int L, int H, int O, int32_t *rels, float *best_opt, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Viterbi -- models/common/crf.py:103-126 (viterbi_decode), per sentence on logits[b,:len].
  * trans[prev*T + cur].  tags [B,L] (entries >= len are set to 0), best [B] or NULL.

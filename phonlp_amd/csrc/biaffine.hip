@@ -253,6 +253,84 @@ __global__ void gather_labels_kernel(const int32_t *lab, const int32_t *heads, c
     rels[idx] = v;
 }
 
+// Labels at the decoded heads: rels[b,i] = argmax_o T[b,i,o,:] . h2[b,heads[b,i],:] -- the only entries of the
+// B x L x L x O label tensor that annotate() reads (ref annotate_model.py:263-266 picks
+// label_argmax[i][head_i]).  One block per word; h2's row is staged in LDS, the four waves take relations
+// o = wave, wave+4, ... and stream T's O*KP-float row once (HBM-bound: 4*O*KP bytes per word).  Strict '>' in
+// ascending o keeps the lowest o on ties.  Words outside 1 <= i < len get 0, as gather_labels_kernel does.
+__global__ __launch_bounds__(256) void label_at_heads_kernel(const float *T, const float *XF, const int32_t *heads,
+                                                              const int32_t *sentlens, int L, int O, int KP,
+                                                              int32_t *rels, float *best_opt) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];
+    __shared__ float wbest[4];
+    __shared__ int warg[4];
+    const int word = blockIdx.x;
+    const int b = word / L, i = word - b * L;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int h = -1;
+    if (i >= 1 && i < sentlens[b]) {
+        h = heads[word];
+        if (h < 0 || h >= L) h = -1;
+    }
+    if (h < 0) {  // block-uniform
+        if (tid == 0) {
+            rels[word] = 0;
+            if (best_opt) best_opt[word] = 0.f;
+        }
+        return;
+    }
+    const int n4 = KP >> 2;
+    const float4 *x2 = reinterpret_cast<const float4 *>(XF + ((long)b * L + h) * 2 * KP + KP);
+    float4 *xs4 = reinterpret_cast<float4 *>(xs);
+    for (int c = tid; c < n4; c += 256) xs4[c] = x2[c];
+    __syncthreads();
+    const float4 *Trow = reinterpret_cast<const float4 *>(T + (long)word * O * KP);
+    float bestv = -INFINITY;
+    int besto = 0;
+    for (int o = wave; o < O; o += 12) {  // three relations per trip: their loads are in flight together
+        float s[3] = {0.f, 0.f, 0.f};
+        for (int c = lane; c < n4; c += 64) {
+            const float4 xv = xs4[c];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int ou = o + 4 * u;
+                if (ou < O) {
+                    const float4 tv = Trow[(long)ou * n4 + c];
+                    s[u] = fmaf(tv.x, xv.x, s[u]);
+                    s[u] = fmaf(tv.y, xv.y, s[u]);
+                    s[u] = fmaf(tv.z, xv.z, s[u]);
+                    s[u] = fmaf(tv.w, xv.w, s[u]);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int ou = o + 4 * u;
+            const float v = wave_sum(s[u]);
+            if (ou < O && v > bestv) {
+                bestv = v;
+                besto = ou;
+            }
+        }
+    }
+    if (lane == 0) {
+        wbest[wave] = bestv;
+        warg[wave] = besto;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float bv = wbest[0];
+        int bo = warg[0];
+        for (int w = 1; w < 4; ++w)
+            if (wbest[w] > bv || (wbest[w] == bv && warg[w] < bo)) {
+                bv = wbest[w];
+                bo = warg[w];
+            }
+        rels[word] = bo;
+        if (best_opt) best_opt[word] = bv;
+    }
+}
+
 }  // namespace phonlp
 
 using namespace phonlp;
@@ -329,6 +407,31 @@ extern "C" int phonlp_deep_biaffine_label(const float *hidden, int D, int B, int
     if (gemm_engine()) hipLaunchKernelGGL(label_kernel<1>, dim3(B * a.tiles * a.tiles), dim3(512), 0, st, a);
     else hipLaunchKernelGGL(label_kernel<0>, dim3(B * a.tiles * a.tiles), dim3(512), 0, st, a);
     return check_launch("label_kernel");
+}
+
+extern "C" int phonlp_label_project(const float *hidden, int D, int B, int L, int H, int O, const float *W12,
+                                    const float *b12, const float *Wbt, float *XF, float *T, void *stream) {
+    if (!hidden || !W12 || !b12 || !Wbt || !XF || !T || B <= 0 || L <= 0 || H <= 0 || D <= 0 || O <= 0)
+        return fail(PHONLP_ERR_SHAPE, "label_project: bad argument");
+    hipStream_t st = as_stream(stream);
+    const int M = B * L, KP = kp_of(H);
+    int rc = launch_linear("linear:label_w12", hidden, D, W12, D, b12, XF, 2L * KP, M, 2 * KP, D, 1, nullptr, 0, st);
+    if (rc) return rc;
+    return launch_linear("linear:label_stage_a", XF, 2L * KP, Wbt, KP, nullptr, T, (long)O * KP, M, O * KP, KP, 0, nullptr, 0, st);
+}
+
+extern "C" int phonlp_label_at_heads(const float *T, const float *XF, const int32_t *heads, const int32_t *sentlens,
+                                     int B, int L, int H, int O, int32_t *rels, float *best_opt, void *stream) {
+    if (!T || !XF || !heads || !sentlens || !rels || B <= 0 || L <= 0 || H <= 0 || O <= 0)
+        return fail(PHONLP_ERR_SHAPE, "label_at_heads: bad argument");
+    const int KP = kp_of(H);
+    if ((size_t)KP * sizeof(float) > 60 * 1024) return fail(PHONLP_ERR_UNSUPPORTED, "label_at_heads: H too large for the LDS row");
+    if (((uintptr_t)T & 15) || ((uintptr_t)XF & 15)) return fail(PHONLP_ERR_SHAPE, "label_at_heads: T, XF must be 16-byte aligned");
+    hipStream_t st = as_stream(stream);
+    ProfScope ps("label_at_heads", st);
+    hipLaunchKernelGGL(label_at_heads_kernel, dim3(B * L), dim3(256), (size_t)KP * sizeof(float), st, T, XF, heads,
+                       sentlens, L, O, KP, rels, best_opt);
+    return check_launch("label_at_heads_kernel");
 }
 
 extern "C" int phonlp_gather_labels(const int32_t *label_argmax, const int32_t *heads, const int32_t *sentlens, int B,

@@ -104,7 +104,8 @@ class TaskHeads:
                 "sentlens": lens}
 
     # ---- JointModel.dep_forward after the gather (ref annotate_model.py:172-215)
-    def parser(self, enc: torch.Tensor, sentlens, want_raw=False, want_label_scores=False) -> Dict[str, torch.Tensor]:
+    def parser(self, enc: torch.Tensor, sentlens, want_raw=False, want_label_scores=False,
+               want_label_argmax=True) -> Dict[str, torch.Tensor]:
         w = self.w
         lens = as_sentlens(sentlens, enc.device)
         feat, _, upos_logits = ops.pos_head(enc.contiguous(), lens, w.upos_hid_w, w.upos_hid_b, w.upos_clf_w,
@@ -112,10 +113,11 @@ class TaskHeads:
         hidden = ops.dep_hidden(feat, lens, w.dep_hid_w, w.dep_hid_b)
         arc_logp, raw = ops.deep_biaffine_arc(hidden, w.arc_W12, w.arc_b12, w.arc_Wbt, w.H, w.n_arc_scorers,
                                               w.linearization, w.distance, want_raw)
-        label_argmax, label_scores = ops.deep_biaffine_label(hidden, w.lab_W12, w.lab_b12, w.lab_Wbt, w.H, w.O,
-                                                             want_label_scores)
-        out = {"arc_logp": arc_logp, "label_argmax": label_argmax, "hidden_out": hidden, "upos_logits": upos_logits,
-               "feat": feat, "sentlens": lens}
+        out = {"arc_logp": arc_logp, "hidden_out": hidden, "upos_logits": upos_logits, "feat": feat, "sentlens": lens}
+        if want_label_argmax or want_label_scores:  # the dense L x L x O contraction (the reference's tensor)
+            label_argmax, label_scores = ops.deep_biaffine_label(hidden, w.lab_W12, w.lab_b12, w.lab_Wbt, w.H, w.O,
+                                                                 want_label_scores)
+            out["label_argmax"] = label_argmax
         if want_raw:
             out["raw"] = raw
         if want_label_scores:
@@ -148,11 +150,12 @@ class TaskHeads:
         the MFMA-bound label path hides them.
         """
         if not overlap:
-            dep = self.parser(enc_dep, sentlens_dep)
+            dep = self.parser(enc_dep, sentlens_dep, want_label_argmax=False)
             tag = self.tagger(enc_tag, sentlens_tag)
             ner, _ = ops.crf_viterbi(tag["ner_logits"], self.w.trans, tag["sentlens"])
             heads, status = ops.mst_one_root(dep["arc_logp"], dep["sentlens"])
-            rels = ops.gather_labels(dep["label_argmax"], heads, dep["sentlens"])
+            XF, T = ops.label_project(dep["hidden_out"], self.w.lab_W12, self.w.lab_b12, self.w.lab_Wbt, self.w.H, self.w.O)
+            rels, _ = ops.label_at_heads(T, XF, heads, dep["sentlens"], self.w.H, self.w.O)
             return {"pos": tag["pos_pred"], "ner": ner, "heads": heads, "rels": rels, "mst_status": status}
         w = self.w
         main = torch.cuda.current_stream()
@@ -185,10 +188,11 @@ class TaskHeads:
             heads, status = ops.mst_one_root(arc_logp, lens_d)
             mst_done = torch.cuda.Event()
             mst_done.record(s_mst)
-        label_argmax, _ = ops.deep_biaffine_label(hidden, w.lab_W12, w.lab_b12, w.lab_Wbt, w.H, w.O, False)
+        XF, T = ops.label_project(hidden, w.lab_W12, w.lab_b12, w.lab_Wbt, w.H, w.O)
         main.wait_event(mst_done)
         main.wait_event(tag_done)
         for t in (heads, status, ner, tag["pos_pred"]):
             t.record_stream(main)
-        rels = ops.gather_labels(label_argmax, heads, lens_d)
+        # labels only where annotate() reads them: at the decoded heads (ref annotate_model.py:263-266)
+        rels, _ = ops.label_at_heads(T, XF, heads, lens_d, w.H, w.O)
         return {"pos": tag["pos_pred"], "ner": ner, "heads": heads, "rels": rels, "mst_status": status}

@@ -208,6 +208,35 @@ def mst_one_root(arc: Tensor, sentlens: Tensor) -> Tuple[Tensor, Tensor]:
     return heads, status
 
 
+@torch.library.custom_op("phonlp_amd::label_project", mutates_args=())
+def label_project(hidden: Tensor, W12: Tensor, b12: Tensor, Wbt: Tensor, H: int, O: int) -> Tuple[Tensor, Tensor]:
+    """hidden [B,L,D] -> (XF [B*L, 2*KP], T [B*L, O*KP]): the label scorer's two GEMMs (include/phonlp_heads.h)."""
+    _need(hidden, torch.float32, "hidden")
+    B, L, D = hidden.shape
+    dev = hidden.device
+    KP = kp(H)
+    XF = torch.empty((B * L, 2 * KP), dtype=torch.float32, device=dev)
+    T = torch.empty((B * L, O * KP), dtype=torch.float32, device=dev)
+    check(lib().phonlp_label_project(_p(hidden), D, B, L, H, O, _p(W12), _p(b12), _p(Wbt), _p(XF), _p(T), _stream()),
+          "phonlp_label_project")
+    return XF, T
+
+
+@torch.library.custom_op("phonlp_amd::label_at_heads", mutates_args=())
+def label_at_heads(T: Tensor, XF: Tensor, heads: Tensor, sentlens: Tensor, H: int, O: int) -> Tuple[Tensor, Tensor]:
+    """-> (rels int32 [B,L], winning score fp32 [B,L]) at j = heads[b,i]; 0 outside 1 <= i < len."""
+    _need(T, torch.float32, "T")
+    _need(XF, torch.float32, "XF")
+    _need(heads, torch.int32, "heads")
+    _need(sentlens, torch.int32, "sentlens")
+    B, L = heads.shape
+    rels = torch.empty((B, L), dtype=torch.int32, device=T.device)
+    best = torch.empty((B, L), dtype=torch.float32, device=T.device)
+    check(lib().phonlp_label_at_heads(_p(T), _p(XF), _p(heads), _p(sentlens), B, L, H, O, _p(rels), _p(best),
+                                      _stream()), "phonlp_label_at_heads")
+    return rels, best
+
+
 @torch.library.custom_op("phonlp_amd::gather_labels", mutates_args=())
 def gather_labels(label_argmax: Tensor, heads: Tensor, sentlens: Tensor) -> Tensor:
     _need(label_argmax, torch.int32, "label_argmax")

@@ -386,6 +386,38 @@ def test_headline_batch_properties(dev, engine):
 
 
 # ------------------------------------------------------------------------------------------ glue kernels (section 8f)
+@pytest.mark.parametrize("B,L,H,O", [(6, 37, 24, 5), (16, 128, 400, 33)])
+def test_label_at_heads_matches_dense_label_scorer(dev, engine, B, L, H, O):
+    """rels from the at-heads contraction == gather of the dense scorer's arg-max at the same heads; where the two
+    disagree the dense scores of the two candidates must be tied to fp32 rounding.  Winning scores agree with the
+    dense tensor to 2e-4 relative (the north-star bar is 1e-3)."""
+    from phonlp_amd import HeadWeights, ops
+    from phonlp_amd import synthetic as S
+    sd = S.make_state_dict(64, 12, H, 7, O, 5, seed=L)
+    w = HeadWeights.from_state_dict(sd, dev)
+    g = torch.Generator().manual_seed(B * L)
+    hidden = torch.randn(B, L, 64 + 12, generator=g).to(dev)
+    lens = torch.randint(2, L + 1, (B,), generator=g).to(torch.int32)
+    lens[0] = L
+    heads = torch.stack([torch.randint(0, int(n), (L,), generator=g) for n in lens]).to(torch.int32)
+    lens_d, heads_d = lens.to(dev), heads.to(dev)
+    dense_arg, scores = ops.deep_biaffine_label(hidden, w.lab_W12, w.lab_b12, w.lab_Wbt, H, O, True)  # [B,L,O,L]
+    want = ops.gather_labels(dense_arg, heads_d, lens_d).cpu()
+    XF, T = ops.label_project(hidden, w.lab_W12, w.lab_b12, w.lab_Wbt, H, O)
+    got, best = ops.label_at_heads(T, XF, heads_d, lens_d, H, O)
+    got, best, scores = got.cpu(), best.cpu(), scores.cpu()
+    for b in range(B):
+        for i in range(L):
+            if not (1 <= i < int(lens[b])):
+                assert got[b, i] == 0
+                continue
+            col = scores[b, i, :, int(heads[b, i])]
+            tol = 2e-4 * float(col.abs().max()) + 1e-6
+            assert abs(float(best[b, i]) - float(col.max())) <= tol
+            if got[b, i] != want[b, i]:
+                assert abs(float(col[got[b, i]]) - float(col[want[b, i]])) <= tol, (b, i)
+
+
 @pytest.mark.parametrize("B,S,L,E,idx_dtype", [(5, 40, 19, 32, torch.int64), (64, 200, 128, 768, torch.int32)])
 def test_gather_first_subword(dev, B, S, L, E, idx_dtype):
     from phonlp_amd import ops
