@@ -3,6 +3,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "mma_f32.h"
 
 namespace phonlp {
@@ -324,6 +326,492 @@ __global__ __launch_bounds__(256, 2) void linear_split_kernel(LinearArgs a) {
     linear_epilogue<TM, TN, WM, WN>(acc, reinterpret_cast<float *>(lds), a, m0, n0, wm, wn, lane, wave);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Engine 1, large layers: 256 x 128 block tile, four waves of 128 x 64, k16 stages, two LDS buffers, ONE
+// barrier per stage, and the split of stage s+1 interleaved with the MFMAs of stage s inside every wave
+// (the matrix pipe runs asynchronously: a wave can issue ~7 VALU/LDS instructions in the shadow of each
+// 32-cycle MFMA).  Per stage and wave: 18 ds_read_b128 feed 48 MFMAs, and the thread splits its 24 staged
+// floats (~130 VALU ops, 2.7 per MFMA -- the 128 x 128 kernel above needs 5.7).
+//
+// LDS (dynamic, 2 x 36 KB): buffer b, plane p at (b*3 + p) * 384*32 bytes; rows 0-255 = A tile, 256-383 = B
+// tile; a plane row is the stage's 16 bf16 (32 bytes) as two 16-byte chunks, chunk c stored at slot
+// c ^ ((row>>3)&1) so that the 16 rows of a ds_read_b128 lane group cover all 64 banks.
+// Rows past M / N are not zero-filled: their pointers are clamped to the last valid row and the garbage only
+// reaches output rows / columns that the epilogue never stores.  Columns past K (last stage only) are
+// clamped to K-4 for the load and zeroed before the split.
+template <int TAG, int ABL = 0>
+__global__ __launch_bounds__(256, 2) void linear_split256_kernel(LinearArgs a) {
+    constexpr int BM = 256, BN = 128, WM = 2, WN = 2, TM = 4, TN = 2, SK = 16;
+    constexpr int ROWS = BM + BN, PLANE = ROWS * 32, BUF = 3 * PLANE;
+    static_assert(WM * WN * 32 * (TN * 32 + 4) * 4 <= 2 * BUF, "epilogue patch must fit");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int ntiles = a.num_m * a.num_n;
+    const int nst = (a.K + SK - 1) / SK;
+    int m0, n0;
+    {
+        const int xg = blockIdx.x & 7, jl = blockIdx.x >> 3;
+        const int q = ntiles >> 3, r = ntiles & 7;
+        const int t = (xg < r ? xg * (q + 1) : r * (q + 1) + (xg - r) * q) + jl;
+        constexpr int GM = 4;
+        const int per_group = GM * a.num_n;
+        const int g = t / per_group;
+        const int first_m = g * GM;
+        const int gsz = (a.num_m - first_m) < GM ? (a.num_m - first_m) : GM;
+        const int in = t - g * per_group;
+        m0 = (first_m + in % gsz) * BM;
+        n0 = (in / gsz) * BN;
+    }
+    // staging map: thread -> float4 column c4 = (tid&3)*4 of rows (tid>>2) + 64q; q 0-3 are A rows, 4-5 B rows
+    const int r0 = tid >> 2, c4 = (tid & 3) * 4;
+    const float *src[6];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int row = m0 + r0 + 64 * q;
+        row = row < a.M ? row : a.M - 1;
+        src[q] = a.X + (long)row * a.ldx;
+    }
+#pragma unroll
+    for (int q = 4; q < 6; ++q) {
+        int row = n0 + r0 + 64 * (q - 4);
+        row = row < a.N ? row : a.N - 1;
+        src[q] = a.W + (long)row * a.ldw;
+    }
+    const int wofs = r0 * 32 + ((((c4 >> 3) ^ (r0 >> 3)) & 1) << 4) + (((c4 >> 2) & 1) << 3);
+    float4 R[6];
+    auto load_stage = [&](int st) {
+        int col = st * SK + c4;
+        col = col < a.K - 4 ? col : a.K - 4;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) R[q] = *reinterpret_cast<const float4 *>(src[q] + col);
+    };
+    auto split_stage = [&](unsigned char *buf) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            uint2 h, m, l;
+            split3_f4(R[q], h, m, l);
+            unsigned char *p = buf + wofs + q * 64 * 32;
+            *reinterpret_cast<uint2 *>(p) = h;
+            *reinterpret_cast<uint2 *>(p + PLANE) = m;
+            *reinterpret_cast<uint2 *>(p + 2 * PLANE) = l;
+        }
+    };
+    auto zero_tail = [&](int st) {  // last stage: the float4 whose columns lie past K
+        if (st * SK + c4 >= a.K) {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) R[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+
+    const int r = lane & 31, hh = lane >> 5;
+    const int rofs = r * 32 + (((hh ^ (r >> 3)) & 1) << 4);
+    const int a_ofs = (wm * 128) * 32 + rofs;
+    const int b_ofs = (BM + wn * 64) * 32 + rofs;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // fragments of one stage: all 18 are read before the stage's LDS stores are issued (the compiler cannot
+    // prove that reads of one buffer and stores to the other do not alias, so source order is issue order)
+    struct Frags {
+        u32x4 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
+    };
+    auto read_frags = [&](const unsigned char *buf, Frags &f) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            f.bh[j] = *reinterpret_cast<const u32x4 *>(buf + b_ofs + j * 1024);
+            f.bl[j] = *reinterpret_cast<const u32x4 *>(buf + 2 * PLANE + b_ofs + j * 1024);
+            f.bm[j] = *reinterpret_cast<const u32x4 *>(buf + PLANE + b_ofs + j * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            f.al[i] = *reinterpret_cast<const u32x4 *>(buf + 2 * PLANE + a_ofs + i * 1024);
+            f.ah[i] = *reinterpret_cast<const u32x4 *>(buf + a_ofs + i * 1024);
+            f.am[i] = *reinterpret_cast<const u32x4 *>(buf + PLANE + a_ofs + i * 1024);
+        }
+    };
+    auto mma_frags = [&](const Frags &f) {
+#pragma unroll
+        for (int ip = 0; ip < TM; ip += 2) {
+#define PHONLP_X6_ROUND(AA, BB)                                    \
+    _Pragma("unroll") for (int i = ip; i < ip + 2; ++i)            \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j)                 \
+        acc[i][j] = PHONLP_BF16_MFMA(f.AA[i], f.BB[j], acc[i][j]);
+            PHONLP_X6_ROUND(al, bh)
+            PHONLP_X6_ROUND(ah, bl)
+            PHONLP_X6_ROUND(am, bm)
+            PHONLP_X6_ROUND(am, bh)
+            PHONLP_X6_ROUND(ah, bm)
+            PHONLP_X6_ROUND(ah, bh)
+#undef PHONLP_X6_ROUND
+        }
+    };
+    // MFMA number n of a stage, in the order mma_frags issues them
+    auto mf = [&](auto N, const Frags &f) {
+        constexpr int n = decltype(N)::value;
+        constexpr int ip = n / 24, rem = n % 24, prod = rem / 4, i = ip * 2 + (rem % 4) / 2, j = rem % 2;
+        const u32x4 &A = prod == 0 ? f.al[i] : (prod == 2 || prod == 3) ? f.am[i] : f.ah[i];
+        const u32x4 &B = (prod == 0 || prod == 3 || prod == 5) ? f.bh[j] : prod == 1 ? f.bl[j] : f.bm[j];
+        acc[i][j] = PHONLP_BF16_MFMA(A, B, acc[i][j]);
+    };
+    auto mma_stage = [&](const unsigned char *buf) {
+        Frags f;
+        read_frags(buf, f);
+        mma_frags(f);
+    };
+
+    // prologue: stage 0 in buffer 0, stage 1 in registers
+    load_stage(0);
+    if (nst == 1) zero_tail(0);
+    split_stage(lds);
+    if (nst > 1) load_stage(1);
+    lds_barrier();
+    int s = 0;
+    // >>> steady-state loop
+    // Steady state: multiply stage s, split stage s+1 into the other buffer, fetch stage s+2.  The issue order is
+    // written out by hand and pinned with sched_barrier: MFMAs execute asynchronously, so the 4-6 VALU / LDS /
+    // VMEM instructions placed after each one run in its 32-cycle shadow (a run of back-to-back MFMAs would
+    // leave the wave's other work for after the last one).  ABL != 0 are timing-only ablations of this loop
+    // (tools/engine_probe.py): 1 = MFMAs only, 2 = + fragment reads and the barrier, 3 = + split and LDS stores.
+#define SB() __builtin_amdgcn_sched_barrier(0)
+#define MF(n) mf(std::integral_constant<int, n>{}, f)
+    Frags f;
+    if constexpr (ABL == 1) read_frags(lds, f);
+    for (; s + 2 < nst; ++s) {
+        unsigned char *cur = lds + (s & 1) * BUF, *nxt = lds + ((s + 1) & 1) * BUF;
+        if constexpr (ABL != 1) read_frags(cur, f);
+        SB();
+        constexpr bool SPLIT = ABL == 0 || ABL == 3;
+        float r1[4], r2[4];
+        unsigned t[4];
+        uint2 ph, pm, pl;
+        // ---- split of R[0]
+        {
+            float x[4] = {R[0].x, R[0].y, R[0].z, R[0].w};
+            if constexpr (SPLIT) {
+                if constexpr (ABL == 3) x[0] += (float)s;  // keeps the split inside the loop
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] = __float_as_uint(x[e]) & 0xFFFF0000u;
+                r1[0] = x[0] - __uint_as_float(t[0]);
+                r1[1] = x[1] - __uint_as_float(t[1]);
+            }
+            if constexpr (SPLIT) {
+                r1[2] = x[2] - __uint_as_float(t[2]);
+                r1[3] = x[3] - __uint_as_float(t[3]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] = __float_as_uint(r1[e]) & 0xFFFF0000u;
+            }
+            if constexpr (SPLIT) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r2[e] = r1[e] - __uint_as_float(t[e]);
+                ph.x = __builtin_amdgcn_perm(__float_as_uint(x[1]), __float_as_uint(x[0]), 0x07060302u);
+                ph.y = __builtin_amdgcn_perm(__float_as_uint(x[3]), __float_as_uint(x[2]), 0x07060302u);
+            }
+            MF(0);
+            SB();
+            if constexpr (SPLIT) {
+                pm.x = __builtin_amdgcn_perm(__float_as_uint(r1[1]), __float_as_uint(r1[0]), 0x07060302u);
+                pm.y = __builtin_amdgcn_perm(__float_as_uint(r1[3]), __float_as_uint(r1[2]), 0x07060302u);
+                pl.x = __builtin_amdgcn_perm(__float_as_uint(r2[1]), __float_as_uint(r2[0]), 0x07060302u);
+                pl.y = __builtin_amdgcn_perm(__float_as_uint(r2[3]), __float_as_uint(r2[2]), 0x07060302u);
+            }
+            MF(1);
+            SB();
+            if constexpr (SPLIT) {
+                unsigned char *p = nxt + wofs + 0 * 64 * 32;
+                *reinterpret_cast<uint2 *>(p) = ph;
+                *reinterpret_cast<uint2 *>(p + PLANE) = pm;
+                *reinterpret_cast<uint2 *>(p + 2 * PLANE) = pl;
+            }
+            MF(2);
+            SB();
+        }
+        // ---- split of R[1]
+        {
+            float x[4] = {R[1].x, R[1].y, R[1].z, R[1].w};
+            if constexpr (SPLIT) {
+                if constexpr (ABL == 3) x[0] += (float)s;  // keeps the split inside the loop
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] = __float_as_uint(x[e]) & 0xFFFF0000u;
+                r1[0] = x[0] - __uint_as_float(t[0]);
+                r1[1] = x[1] - __uint_as_float(t[1]);
+            }
+            MF(3);
+            SB();
+            if constexpr (SPLIT) {
+                r1[2] = x[2] - __uint_as_float(t[2]);
+                r1[3] = x[3] - __uint_as_float(t[3]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] = __float_as_uint(r1[e]) & 0xFFFF0000u;
+            }
+            MF(4);
+            SB();
+            if constexpr (SPLIT) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r2[e] = r1[e] - __uint_as_float(t[e]);
+                ph.x = __builtin_amdgcn_perm(__float_as_uint(x[1]), __float_as_uint(x[0]), 0x07060302u);
+                ph.y = __builtin_amdgcn_perm(__float_as_uint(x[3]), __float_as_uint(x[2]), 0x07060302u);
+            }
+            MF(5);
+            SB();
+            if constexpr (SPLIT) {
+                pm.x = __builtin_amdgcn_perm(__float_as_uint(r1[1]), __float_as_uint(r1[0]), 0x07060302u);
+                pm.y = __builtin_amdgcn_perm(__float_as_uint(r1[3]), __float_as_uint(r1[2]), 0x07060302u);
+                pl.x = __builtin_amdgcn_perm(__float_as_uint(r2[1]), __float_as_uint(r2[0]), 0x07060302u);
+                pl.y = __builtin_amdgcn_perm(__float_as_uint(r2[3]), __float_as_uint(r2[2]), 0x07060302u);
+            }
+            MF(6);
+            SB();
+            if constexpr (SPLIT) {
+                unsigned char *p = nxt + wofs + 1 * 64 * 32;
+                *reinterpret_cast<uint2 *>(p) = ph;
+                *reinterpret_cast<uint2 *>(p + PLANE) = pm;
+                *reinterpret_cast<uint2 *>(p + 2 * PLANE) = pl;
+            }
+            MF(7);
+            SB();
+        }
+        // ---- split of R[2]
+        {
+            float x[4] = {R[2].x, R[2].y, R[2].z, R[2].w};
+            if constexpr (SPLIT) {
+                if constexpr (ABL == 3) x[0] += (float)s;  // keeps the split inside the loop
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] = __float_as_uint(x[e]) & 0xFFFF0000u;
+                r1[0] = x[0] - __uint_as_float(t[0]);
+                r1[1] = x[1] - __uint_as_float(t[1]);
+            }
+            MF(8);
+            SB();
+            if constexpr (SPLIT) {
+                r1[2] = x[2] - __uint_as_float(t[2]);
+                r1[3] = x[3] - __uint_as_float(t[3]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] = __float_as_uint(r1[e]) & 0xFFFF0000u;
+            }
+            MF(9);
+            SB();
+            if constexpr (SPLIT) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r2[e] = r1[e] - __uint_as_float(t[e]);
+                ph.x = __builtin_amdgcn_perm(__float_as_uint(x[1]), __float_as_uint(x[0]), 0x07060302u);
+                ph.y = __builtin_amdgcn_perm(__float_as_uint(x[3]), __float_as_uint(x[2]), 0x07060302u);
+            }
+            MF(10);
+            SB();
+            if constexpr (SPLIT) {
+                pm.x = __builtin_amdgcn_perm(__float_as_uint(r1[1]), __float_as_uint(r1[0]), 0x07060302u);
+                pm.y = __builtin_amdgcn_perm(__float_as_uint(r1[3]), __float_as_uint(r1[2]), 0x07060302u);
+                pl.x = __builtin_amdgcn_perm(__float_as_uint(r2[1]), __float_as_uint(r2[0]), 0x07060302u);
+                pl.y = __builtin_amdgcn_perm(__float_as_uint(r2[3]), __float_as_uint(r2[2]), 0x07060302u);
+            }
+            MF(11);
+            SB();
+            if constexpr (SPLIT) {
+                unsigned char *p = nxt + wofs + 2 * 64 * 32;
+                *reinterpret_cast<uint2 *>(p) = ph;
+                *reinterpret_cast<uint2 *>(p + PLANE) = pm;
+                *reinterpret_cast<uint2 *>(p + 2 * PLANE) = pl;
+            }
+            MF(12);
+            SB();
+        }
+        // ---- split of R[3]
+        {
+            float x[4] = {R[3].x, R[3].y, R[3].z, R[3].w};
+            if constexpr (SPLIT) {
+                if constexpr (ABL == 3) x[0] += (float)s;  // keeps the split inside the loop
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] = __float_as_uint(x[e]) & 0xFFFF0000u;
+                r1[0] = x[0] - __uint_as_float(t[0]);
+                r1[1] = x[1] - __uint_as_float(t[1]);
+            }
+            MF(13);
+            SB();
+            if constexpr (SPLIT) {
+                r1[2] = x[2] - __uint_as_float(t[2]);
+                r1[3] = x[3] - __uint_as_float(t[3]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] = __float_as_uint(r1[e]) & 0xFFFF0000u;
+            }
+            MF(14);
+            SB();
+            if constexpr (SPLIT) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r2[e] = r1[e] - __uint_as_float(t[e]);
+                ph.x = __builtin_amdgcn_perm(__float_as_uint(x[1]), __float_as_uint(x[0]), 0x07060302u);
+                ph.y = __builtin_amdgcn_perm(__float_as_uint(x[3]), __float_as_uint(x[2]), 0x07060302u);
+            }
+            MF(15);
+            SB();
+            if constexpr (SPLIT) {
+                pm.x = __builtin_amdgcn_perm(__float_as_uint(r1[1]), __float_as_uint(r1[0]), 0x07060302u);
+                pm.y = __builtin_amdgcn_perm(__float_as_uint(r1[3]), __float_as_uint(r1[2]), 0x07060302u);
+                pl.x = __builtin_amdgcn_perm(__float_as_uint(r2[1]), __float_as_uint(r2[0]), 0x07060302u);
+                pl.y = __builtin_amdgcn_perm(__float_as_uint(r2[3]), __float_as_uint(r2[2]), 0x07060302u);
+            }
+            MF(16);
+            SB();
+            if constexpr (SPLIT) {
+                unsigned char *p = nxt + wofs + 3 * 64 * 32;
+                *reinterpret_cast<uint2 *>(p) = ph;
+                *reinterpret_cast<uint2 *>(p + PLANE) = pm;
+                *reinterpret_cast<uint2 *>(p + 2 * PLANE) = pl;
+            }
+            MF(17);
+            SB();
+        }
+        // ---- split of R[4]
+        {
+            float x[4] = {R[4].x, R[4].y, R[4].z, R[4].w};
+            if constexpr (SPLIT) {
+                if constexpr (ABL == 3) x[0] += (float)s;  // keeps the split inside the loop
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] = __float_as_uint(x[e]) & 0xFFFF0000u;
+                r1[0] = x[0] - __uint_as_float(t[0]);
+                r1[1] = x[1] - __uint_as_float(t[1]);
+            }
+            MF(18);
+            SB();
+            if constexpr (SPLIT) {
+                r1[2] = x[2] - __uint_as_float(t[2]);
+                r1[3] = x[3] - __uint_as_float(t[3]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] = __float_as_uint(r1[e]) & 0xFFFF0000u;
+            }
+            MF(19);
+            SB();
+            if constexpr (SPLIT) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r2[e] = r1[e] - __uint_as_float(t[e]);
+                ph.x = __builtin_amdgcn_perm(__float_as_uint(x[1]), __float_as_uint(x[0]), 0x07060302u);
+                ph.y = __builtin_amdgcn_perm(__float_as_uint(x[3]), __float_as_uint(x[2]), 0x07060302u);
+            }
+            MF(20);
+            SB();
+            if constexpr (SPLIT) {
+                pm.x = __builtin_amdgcn_perm(__float_as_uint(r1[1]), __float_as_uint(r1[0]), 0x07060302u);
+                pm.y = __builtin_amdgcn_perm(__float_as_uint(r1[3]), __float_as_uint(r1[2]), 0x07060302u);
+                pl.x = __builtin_amdgcn_perm(__float_as_uint(r2[1]), __float_as_uint(r2[0]), 0x07060302u);
+                pl.y = __builtin_amdgcn_perm(__float_as_uint(r2[3]), __float_as_uint(r2[2]), 0x07060302u);
+            }
+            MF(21);
+            SB();
+            if constexpr (SPLIT) {
+                unsigned char *p = nxt + wofs + 4 * 64 * 32;
+                *reinterpret_cast<uint2 *>(p) = ph;
+                *reinterpret_cast<uint2 *>(p + PLANE) = pm;
+                *reinterpret_cast<uint2 *>(p + 2 * PLANE) = pl;
+            }
+            MF(22);
+            SB();
+        }
+        // ---- split of R[5]
+        {
+            float x[4] = {R[5].x, R[5].y, R[5].z, R[5].w};
+            if constexpr (SPLIT) {
+                if constexpr (ABL == 3) x[0] += (float)s;  // keeps the split inside the loop
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] = __float_as_uint(x[e]) & 0xFFFF0000u;
+                r1[0] = x[0] - __uint_as_float(t[0]);
+                r1[1] = x[1] - __uint_as_float(t[1]);
+            }
+            MF(23);
+            SB();
+            if constexpr (SPLIT) {
+                r1[2] = x[2] - __uint_as_float(t[2]);
+                r1[3] = x[3] - __uint_as_float(t[3]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] = __float_as_uint(r1[e]) & 0xFFFF0000u;
+            }
+            MF(24);
+            SB();
+            if constexpr (SPLIT) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r2[e] = r1[e] - __uint_as_float(t[e]);
+                ph.x = __builtin_amdgcn_perm(__float_as_uint(x[1]), __float_as_uint(x[0]), 0x07060302u);
+                ph.y = __builtin_amdgcn_perm(__float_as_uint(x[3]), __float_as_uint(x[2]), 0x07060302u);
+            }
+            MF(25);
+            SB();
+            if constexpr (SPLIT) {
+                pm.x = __builtin_amdgcn_perm(__float_as_uint(r1[1]), __float_as_uint(r1[0]), 0x07060302u);
+                pm.y = __builtin_amdgcn_perm(__float_as_uint(r1[3]), __float_as_uint(r1[2]), 0x07060302u);
+                pl.x = __builtin_amdgcn_perm(__float_as_uint(r2[1]), __float_as_uint(r2[0]), 0x07060302u);
+                pl.y = __builtin_amdgcn_perm(__float_as_uint(r2[3]), __float_as_uint(r2[2]), 0x07060302u);
+            }
+            MF(26);
+            SB();
+            if constexpr (SPLIT) {
+                unsigned char *p = nxt + wofs + 5 * 64 * 32;
+                *reinterpret_cast<uint2 *>(p) = ph;
+                *reinterpret_cast<uint2 *>(p + PLANE) = pm;
+                *reinterpret_cast<uint2 *>(p + 2 * PLANE) = pl;
+            }
+            MF(27);
+            SB();
+        }
+        int col = (s + 2) * SK + c4;
+        col = col < a.K - 4 ? col : a.K - 4;
+        if constexpr (ABL == 0) R[0] = *reinterpret_cast<const float4 *>(src[0] + col);
+        MF(28);
+        SB();
+        if constexpr (ABL == 0) R[1] = *reinterpret_cast<const float4 *>(src[1] + col);
+        MF(29);
+        SB();
+        if constexpr (ABL == 0) R[2] = *reinterpret_cast<const float4 *>(src[2] + col);
+        MF(30);
+        SB();
+        if constexpr (ABL == 0) R[3] = *reinterpret_cast<const float4 *>(src[3] + col);
+        MF(31);
+        SB();
+        if constexpr (ABL == 0) R[4] = *reinterpret_cast<const float4 *>(src[4] + col);
+        MF(32);
+        SB();
+        if constexpr (ABL == 0) R[5] = *reinterpret_cast<const float4 *>(src[5] + col);
+        MF(33);
+        SB();
+        // the remaining MFMAs, bare
+        MF(34);
+        MF(35);
+        MF(36);
+        MF(37);
+        MF(38);
+        MF(39);
+        MF(40);
+        MF(41);
+        MF(42);
+        MF(43);
+        MF(44);
+        MF(45);
+        MF(46);
+        MF(47);
+        SB();
+        if constexpr (ABL != 1) lds_barrier();
+    }
+#undef MF
+#undef SB
+    // <<< steady-state loop
+    if (s + 1 < nst) {  // stage nst-2: the last stage is in registers
+        unsigned char *cur = lds + (s & 1) * BUF, *nxt = lds + ((s + 1) & 1) * BUF;
+        zero_tail(s + 1);
+        split_stage(nxt);
+        mma_stage(cur);
+        lds_barrier();
+        ++s;
+    }
+    mma_stage(lds + (s & 1) * BUF);
+    lds_barrier();
+    linear_epilogue<TM, TN, WM, WN>(acc, reinterpret_cast<float *>(lds), a, m0, n0, wm, wn, lane, wave);
+}
+
 // GEMM engine shared by every MFMA kernel of the library: 0 = f32 MFMA (exact fp32 chain), 1 = bf16x6 (default).
 static int g_engine = -1;
 int gemm_engine() {
@@ -364,7 +852,31 @@ int launch_linear(const char *tag, const float *X, long ldx, const float *W, lon
         a.num_n = ceil_div(N, 128);
         const dim3 g(persistent_grid(a.num_m * a.num_n));
         static const bool in_regs = getenv("PHONLP_X6_IN_REGS") != nullptr;  // A/B switch: split per fragment use
+        static const bool small_tile = getenv("PHONLP_X6_TILE128") != nullptr;  // A/B switch: 128 x 128 split kernel
         const dim3 g1(a.num_m * a.num_n);
+        if (eng && !in_regs && !small_tile && M >= 1024 && K >= 8) {
+            static bool attr_set = false;
+            constexpr int LDS = 2 * 3 * 384 * 32;
+            if (!attr_set) {
+                if (hipFuncSetAttribute((const void *)linear_split256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess ||
+                    hipFuncSetAttribute((const void *)linear_split256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+                    return fail(PHONLP_ERR_LAUNCH, "linear: cannot raise the dynamic LDS limit");
+                attr_set = true;
+            }
+            a.num_m = ceil_div(M, 256);
+            const dim3 g2(a.num_m * a.num_n);
+            static const int abl = getenv("PHONLP_X6_ABLATION") ? atoi(getenv("PHONLP_X6_ABLATION")) : 0;  // timing only
+            if (abl) {
+                const void *fns[] = {(const void *)linear_split256_kernel<0, 1>, (const void *)linear_split256_kernel<0, 2>,
+                                     (const void *)linear_split256_kernel<0, 3>};
+                for (const void *f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+                if (abl == 1) hipLaunchKernelGGL((linear_split256_kernel<0, 1>), g2, dim3(256), LDS, stream, a);
+                else if (abl == 2) hipLaunchKernelGGL((linear_split256_kernel<0, 2>), g2, dim3(256), LDS, stream, a);
+                else hipLaunchKernelGGL((linear_split256_kernel<0, 3>), g2, dim3(256), LDS, stream, a);
+            } else if (stage_a) hipLaunchKernelGGL((linear_split256_kernel<1>), g2, dim3(256), LDS, stream, a);
+            else hipLaunchKernelGGL((linear_split256_kernel<0>), g2, dim3(256), LDS, stream, a);
+            return check_launch("linear_split256_kernel");
+        }
         if (stage_a) {
             if (eng && !in_regs) hipLaunchKernelGGL((linear_split_kernel<1>), g1, dim3(256), 0, stream, a);
             else if (eng) hipLaunchKernelGGL((linear_kernel<128, 128, 2, 2, 1, 1>), g, dim3(256), 0, stream, a);

@@ -47,7 +47,8 @@ def _close(got, want, rtol=2e-4, atol=2e-5):
 # ------------------------------------------------------------------------------------------ dense layer
 @pytest.mark.parametrize("M,N,K,relu,masked", [
     (300, 70, 868, True, False), (129, 9, 868, True, True), (64, 416, 416, False, False),
-    (1000, 868, 868, False, True), (257, 24, 400, False, True), (128, 128, 32, True, False), (5, 3, 4, False, False),
+    (1000, 868, 868, False, True), (257, 24, 400, False, True), (1500, 300, 868, True, True), (1027, 129, 20, False, False),
+    (2048, 128, 4, False, False), (128, 128, 32, True, False), (5, 3, 4, False, False),
 ])
 def test_linear_vs_torch_fp32(dev, engine, M, N, K, relu, masked):
     from phonlp_amd import ops
@@ -68,7 +69,7 @@ def test_linear_vs_torch_fp32(dev, engine, M, N, K, relu, masked):
     torch.testing.assert_close(got.cpu(), ref, rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("M,N,K", [(512, 640, 401), (256, 868, 868), (384, 256, 4096)])
+@pytest.mark.parametrize("M,N,K", [(512, 640, 401), (256, 868, 868), (384, 256, 4096), (1300, 650, 401), (1024, 256, 2048)])
 def test_engines_against_fp64(dev, M, N, K):
     """Both matrix engines are fp32-grade: error against an fp64 product, in units of sum_k |a||b| (the scale an
     fp32 dot product's rounding error lives on), stays below 1e-6, and the bf16-split engine is no worse than
