@@ -175,7 +175,7 @@ def main():
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("linear:label_stage_a")
+            traffic = json.load(open(tpath)).get(f"linear:label_stage_a@engine{engine}")
         res = {
             "metric": "sentences/sec through POS+NER+dep heads at B=256,L=128",
             "value": sent / elapsed, "unit": "sentences/s", "n_gpus": world, "steps": args.steps,
