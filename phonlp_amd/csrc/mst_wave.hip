@@ -69,6 +69,29 @@ __device__ __forceinline__ int row_argmax16(const double *S, int pitch, const in
     return bi;
 }
 
+// The same arg-max with the lane's column slots (node[sub + 16 t]) already in registers: all of the row's loads
+// are issued together instead of as a chain of dependent (slot, value) pairs.  Same comparison order.
+template <int NC>
+__device__ __forceinline__ int row_argmax16_cols(const double *S, int pitch, int rs, const int (&cols)[NC], int n,
+                                                 int sub) {
+    double vals[NC];
+#pragma unroll
+    for (int t = 0; t < NC; ++t) vals[t] = (sub + 16 * t < n) ? S[(long)rs * pitch + cols[t]] : NEG_INF_D;
+    double bv = NEG_INF_D;
+    int bi = INT_MAX;
+    if (sub < n) { bv = vals[0]; bi = sub; }
+#pragma unroll
+    for (int t = 1; t < NC; ++t)
+        if (sub + 16 * t < n && vals[t] > bv) { bv = vals[t]; bi = sub + 16 * t; }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+        const double v2 = __shfl_xor(bv, o, 16);
+        const int i2 = __shfl_xor(bi, o, 16);
+        if (v2 > bv || (v2 == bv && i2 < bi)) { bv = v2; bi = i2; }
+    }
+    return bi;
+}
+
 template <int NPL>
 __global__ __launch_bounds__(256) void mst_wave_kernel(MstArgs a, int stack_cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -83,6 +106,10 @@ __global__ __launch_bounds__(256) void mst_wave_kernel(MstArgs a, int stack_cap)
         if (tid == 0) a.status[b] = l == 1 ? PHONLP_MST_NO_FINITE_TREE : PHONLP_MST_OK;
         return;
     }
+#ifdef MST_STAMPS
+    long long stamp_acc[16] = {0};
+    long long stamp_t = clock64();
+#endif
     double *S = reinterpret_cast<double *>(smem_raw);
     double *edge = S + (long)L * pitch;
     int *node = reinterpret_cast<int *>(edge + L);
@@ -116,51 +143,62 @@ __global__ __launch_bounds__(256) void mst_wave_kernel(MstArgs a, int stack_cap)
         }
         for (int t = tid; t < l; t += 256) node[t] = t;
         __syncthreads();
+        STAMP(0);
         for (int row = tid >> 4; row < l; row += 16) {
             const int bi = row_argmax16(S, pitch, node, row, l, sub);
             if (sub == 0) hdA[row] = bi;
         }
         __syncthreads();
+        STAMP(1);
 
         if (wave == 0) {
             int n = l, levels = 0, used = 0;
             // ------------------------------------------------------------------ contraction loop
             for (;;) {
-                // cycles by pointer doubling on packed (min index << 16 | pointer) words
+                // cycles by pointer doubling on packed (min index << 16 | pointer) words, one word per owned node
+                // in registers; the gather "word of the node I point at" is a ds_bpermute per owner register
+                int word[NPL];
 #pragma unroll
                 for (int q = 0; q < NPL; ++q) {
                     const int v = lane + 64 * q;
-                    if (v < n) { pk0[v] = hdA[v] | (v << 16); flag[v] = 0; }
+                    word[q] = 0;
+                    if (v < n) { word[q] = hdA[v] | (v << 16); flag[v] = 0; }
                 }
-                WFENCE();
-                int *pc = pk0, *pn = pk1;
                 for (int span = 1; span < n; span <<= 1) {
+                    int nw[NPL];
 #pragma unroll
                     for (int q = 0; q < NPL; ++q) {
-                        const int v = lane + 64 * q;
-                        if (v < n) {
-                            const int x = pc[v];
-                            const int y = pc[x & 0xFFFF];
-                            const int mx = x >> 16, my = y >> 16;
-                            pn[v] = (y & 0xFFFF) | ((mx < my ? mx : my) << 16);
+                        const int x = word[q];
+                        const int tn = x & 0xFFFF;
+                        int y = __shfl(word[0], tn & 63);
+#pragma unroll
+                        for (int q2 = 1; q2 < NPL; ++q2) {
+                            const int y2 = __shfl(word[q2], tn & 63);
+                            if ((tn >> 6) == q2) y = y2;
                         }
+                        const int mx = x >> 16, my = y >> 16;
+                        nw[q] = (y & 0xFFFF) | ((mx < my ? mx : my) << 16);
                     }
-                    WFENCE();
-                    int *t = pc; pc = pn; pn = t;
+#pragma unroll
+                    for (int q = 0; q < NPL; ++q) word[q] = nw[q];
                 }
+                WFENCE();
 #pragma unroll
                 for (int q = 0; q < NPL; ++q) {
                     const int v = lane + 64 * q;
-                    if (v < n) flag[pc[v] & 0xFFFF] = 1;
+                    if (v < n) flag[word[q] & 0xFFFF] = 1;
                 }
                 WFENCE();
                 int M = 0;
+                int oncyc[NPL];
 #pragma unroll
                 for (int q = 0; q < NPL; ++q) {
                     const int v = lane + 64 * q;
-                    if (v < n && flag[v]) { const int m = pc[v] >> 16; M = m > M ? m : M; }
+                    oncyc[q] = (v < n) ? flag[v] : 0;
+                    if (oncyc[q]) { const int m = word[q] >> 16; M = m > M ? m : M; }
                 }
                 M = wave_max_i(M);
+                STAMP(2);
                 if (M == 0) break;
                 if (levels >= l) { err = 1; break; }
                 // the chosen cycle; member / outside lists in ascending logical order
@@ -168,7 +206,7 @@ __global__ __launch_bounds__(256) void mst_wave_kernel(MstArgs a, int stack_cap)
 #pragma unroll
                 for (int q = 0; q < NPL; ++q) {
                     const int v = lane + 64 * q;
-                    const int f = (v < n && flag[v] && (pc[v] >> 16) == M) ? 1 : 0;
+                    const int f = (oncyc[q] && (word[q] >> 16) == M) ? 1 : 0;
                     const unsigned long long bal = __ballot(f);
                     const int rc = c + __popcll(bal & lt_mask);
                     if (v < n) {
@@ -180,6 +218,7 @@ __global__ __launch_bounds__(256) void mst_wave_kernel(MstArgs a, int stack_cap)
                 }
                 const int k = n - c;
                 WFENCE();
+                STAMP(3);
                 // cycle edge scores and their numpy-ordered sum (ref :73-75)
                 for (int x = lane; x < c; x += 64) {
                     const int v = cyc[x];
@@ -187,15 +226,28 @@ __global__ __launch_bounds__(256) void mst_wave_kernel(MstArgs a, int stack_cap)
                 }
                 WFENCE();
                 const double total = np_sum<4>(edge, c);  // every lane, broadcast LDS reads
+                STAMP(4);
                 // expansion record of this level
-                unsigned char *rec;
-                if (used + 2 * n <= stack_cap) { rec = lstack + used; lvl_off[levels] = used; used += 2 * n; }
-                else { rec = gstack + (long)levels * gstride; lvl_off[levels] = -1; }
+                // record stores go through REC_ST: one wave-uniform branch per store site instead of a pointer that
+                // may be LDS or global (which hipcc can only serve with flat_ instructions)
+                const bool rec_lds = used + 2 * n <= stack_cap;
+                unsigned char *rec_l = lstack + used;
+                unsigned char *rec_g = gstack + (long)levels * gstride;
+                if (rec_lds) { if (lane == 0) lvl_off[levels] = used; used += 2 * n; }
+                else if (lane == 0) lvl_off[levels] = -1;
+#define REC_ST(i, v) do { if (rec_lds) rec_l[i] = (unsigned char)(v); else rec_g[i] = (unsigned char)(v); } while (0)
                 if (lane == 0) { lvl_n[levels] = n; lvl_c[levels] = c; }
-                unsigned char *r_cyc = rec, *r_hd = rec + c, *r_ep = rec + 2 * c, *r_lp = r_ep + k;
-                for (int x = lane; x < c; x += 64) { r_cyc[x] = (unsigned char)cyc[x]; r_hd[x] = (unsigned char)hdA[cyc[x]]; }
+                for (int x = lane; x < c; x += 64) { REC_ST(x, cyc[x]); REC_ST(c + x, hdA[cyc[x]]); }
                 // best way into the cycle from every outside node / best head inside it (ref :84-99)
                 const int ms = node[cyc[0]];
+                constexpr int CU = 4;  // members handled with all loads in flight (cycles of 2-3 nodes dominate)
+                int csm[CU];
+                double em[CU];
+#pragma unroll
+                for (int m = 0; m < CU; ++m) {
+                    csm[m] = m < c ? node[cyc[m]] : ms;
+                    em[m] = m < c ? edge[m] : 0.0;
+                }
                 int my_slot[NPL], my_newhead[NPL], my_need[NPL];
                 double my_ev[NPL], my_lv[NPL];
 #pragma unroll
@@ -205,11 +257,25 @@ __global__ __launch_bounds__(256) void mst_wave_kernel(MstArgs a, int stack_cap)
                     if (x < k) {
                         const int old = rest[x];
                         const int slot = node[old];
-                        const int c0 = node[cyc[0]];
-                        double be = (SM(c0, slot) - edge[0]) + total;
-                        double bl = SM(slot, c0);
+                        const int h = hdA[old];
+                        double se[CU], sl[CU];
+#pragma unroll
+                        for (int m = 0; m < CU; ++m) {
+                            se[m] = SM(csm[m], slot);
+                            sl[m] = SM(slot, csm[m]);
+                        }
+                        double be = (se[0] - em[0]) + total;
+                        double bl = sl[0];
                         int ae = 0, al = 0;
-                        for (int m = 1; m < c; ++m) {
+#pragma unroll
+                        for (int m = 1; m < CU; ++m) {
+                            if (m < c) {
+                                const double ve = (se[m] - em[m]) + total;
+                                if (ve > be) { be = ve; ae = m; }
+                                if (sl[m] > bl) { bl = sl[m]; al = m; }
+                            }
+                        }
+                        for (int m = CU; m < c; ++m) {
                             const int cs = node[cyc[m]];
                             const double ve = (SM(cs, slot) - edge[m]) + total;
                             if (ve > be) { be = ve; ae = m; }
@@ -217,13 +283,13 @@ __global__ __launch_bounds__(256) void mst_wave_kernel(MstArgs a, int stack_cap)
                             if (vl > bl) { bl = vl; al = m; }
                         }
                         my_slot[q] = slot; my_ev[q] = be; my_lv[q] = bl;
-                        r_ep[x] = (unsigned char)ae;
-                        r_lp[x] = (unsigned char)al;
-                        const int h = hdA[old];
+                        REC_ST(2 * c + x, ae);
+                        REC_ST(2 * c + k + x, al);
                         if (incyc[h]) my_need[q] = 1; else my_newhead[q] = rankr[h];
                     }
                 }
                 WFENCE();
+                STAMP(5);
                 // contract in place; rows that pointed into the cycle (and the metanode) go on the rescan list
                 int nneed = 0;
 #pragma unroll
@@ -245,13 +311,23 @@ __global__ __launch_bounds__(256) void mst_wave_kernel(MstArgs a, int stack_cap)
                 n = k + 1;
                 ++levels;
                 WFENCE();
-                for (int p = 0; p < nneed; p += 4) {
-                    const int idx = p + (lane >> 4);
-                    const int row = idx < nneed ? needl[idx] : 0;
-                    const int bi = row_argmax16(S, pitch, node, row, n, sub);
-                    if (idx < nneed && sub == 0) hdA[row] = bi;
+                STAMP(6);
+#ifdef MST_STAMPS
+                if (tid == 0) { stamp_acc[10] += 1; stamp_acc[13] += nneed; }
+#endif
+                {
+                    int cols[4 * NPL];
+#pragma unroll
+                    for (int t = 0; t < 4 * NPL; ++t) cols[t] = (sub + 16 * t < n) ? node[sub + 16 * t] : 0;
+                    for (int p = 0; p < nneed; p += 4) {
+                        const int idx = p + (lane >> 4);
+                        const int row = idx < nneed ? needl[idx] : 0;
+                        const int bi = row_argmax16_cols<4 * NPL>(S, pitch, node[row], cols, n, sub);
+                        if (idx < nneed && sub == 0) hdA[row] = bi;
+                    }
                 }
                 WFENCE();
+                STAMP(12);
             }
             // ------------------------------------------------------------------ expansion (ref :105-128)
             int *cur = hdA, *oth = hdB;
@@ -260,45 +336,81 @@ __global__ __launch_bounds__(256) void mst_wave_kernel(MstArgs a, int stack_cap)
                 for (int lev = levels - 1; lev >= 0; --lev) {
                     const int np_ = lvl_n[lev], c = lvl_c[lev], k = np_ - c;
                     const int off = lvl_off[lev];
-                    const unsigned char *rec = off >= 0 ? lstack + off : gstack + (long)lev * gstride;
+                    // instantiated once per address space (LDS stack / global spill), so the record reads are
+                    // ds_read_u8 or global_load_ubyte rather than flat loads
+                    auto expand_level = [&](const unsigned char *rec) __attribute__((always_inline)) {
                     const unsigned char *r_cyc = rec, *r_hd = rec + c, *r_ep = rec + 2 * c, *r_lp = r_ep + k;
+                    constexpr int CE = 4;
+                    if (c <= CE) {
+                        // rest[x] = x + #{j : member_j - j <= x} (members ascending), straight from the record; the
+                        // metanode's pick is folded into the member loop: one store phase, one fence per level
+                        int thr[CE];
 #pragma unroll
-                    for (int q = 0; q < NPL; ++q) {
-                        const int v = lane + 64 * q;
-                        if (v < np_) flag[v] = 0;
-                    }
-                    WFENCE();
-                    for (int x = lane; x < c; x += 64) flag[r_cyc[x]] = 1;
-                    WFENCE();
-                    int base = 0;
+                        for (int j = 0; j < CE; ++j) thr[j] = j < c ? (int)r_cyc[j] - j : INT_MAX;
+                        auto rest_of = [&](int x) {
+                            int r = x;
 #pragma unroll
-                    for (int q = 0; q < NPL; ++q) {
-                        const int v = lane + 64 * q;
-                        const int f = (v < np_ && flag[v]) ? 1 : 0;
-                        const unsigned long long bal = __ballot(f);
-                        const int rc = base + __popcll(bal & lt_mask);
-                        if (v < np_ && !f) rest[v - rc] = v;
-                        base += __popcll(bal);
-                    }
-                    WFENCE();
-#pragma unroll
-                    for (int q = 0; q < NPL; ++q) {
-                        const int x = lane + 64 * q;
-                        if (x < k) {
-                            const int sx = cur[x];
-                            oth[rest[x]] = sx < k ? rest[sx] : (int)r_cyc[r_lp[x]];
-                        }
-                    }
-                    for (int x = lane; x < c; x += 64) oth[r_cyc[x]] = r_hd[x];
-                    WFENCE();
-                    if (lane == 0) {
+                            for (int j = 0; j < CE; ++j) r += (x >= thr[j]) ? 1 : 0;
+                            return r;
+                        };
                         const int mh = cur[k];
-                        oth[r_cyc[r_ep[mh]]] = rest[mh];
+                        const int ep = r_ep[mh];
+#pragma unroll
+                        for (int q = 0; q < NPL; ++q) {
+                            const int x = lane + 64 * q;
+                            if (x < k) {
+                                const int sx = cur[x];
+                                oth[rest_of(x)] = sx < k ? rest_of(sx) : (int)r_cyc[r_lp[x]];
+                            }
+                        }
+                        if (lane < c) oth[r_cyc[lane]] = lane == ep ? rest_of(mh) : (int)r_hd[lane];
+                        WFENCE();
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < NPL; ++q) {
+                            const int v = lane + 64 * q;
+                            if (v < np_) flag[v] = 0;
+                        }
+                        WFENCE();
+                        for (int x = lane; x < c; x += 64) flag[r_cyc[x]] = 1;
+                        WFENCE();
+                        int base = 0;
+#pragma unroll
+                        for (int q = 0; q < NPL; ++q) {
+                            const int v = lane + 64 * q;
+                            const int f = (v < np_ && flag[v]) ? 1 : 0;
+                            const unsigned long long bal = __ballot(f);
+                            const int rc = base + __popcll(bal & lt_mask);
+                            if (v < np_ && !f) rest[v - rc] = v;
+                            base += __popcll(bal);
+                        }
+                        WFENCE();
+#pragma unroll
+                        for (int q = 0; q < NPL; ++q) {
+                            const int x = lane + 64 * q;
+                            if (x < k) {
+                                const int sx = cur[x];
+                                oth[rest[x]] = sx < k ? rest[sx] : (int)r_cyc[r_lp[x]];
+                            }
+                        }
+                        for (int x = lane; x < c; x += 64) oth[r_cyc[x]] = r_hd[x];
+                        WFENCE();
+                        if (lane == 0) {
+                            const int mh = cur[k];
+                            oth[r_cyc[r_ep[mh]]] = rest[mh];
+                        }
+                        WFENCE();
                     }
-                    WFENCE();
+                    };
+                    if (off >= 0) expand_level(lstack + off);
+                    else expand_level(gstack + (long)lev * gstride);
                     int *t = cur; cur = oth; oth = t;
                 }
             }
+            STAMP(7);
+#ifdef MST_STAMPS
+            if (tid == 0) stamp_acc[11] += 1;
+#endif
             // ------------------------------------------------------------------ single-root logic (ref :137-169)
             int next = INT_MAX, done = 0;
             if (err) {
@@ -373,8 +485,13 @@ __global__ __launch_bounds__(256) void mst_wave_kernel(MstArgs a, int stack_cap)
             }
             if (done == 2 && lane == 0) a.status[b] = 2;
             if (lane == 0) { sc[WS_NEXT] = next; sc[WS_DONE] = done; }
+            STAMP(8);
         }
         __syncthreads();
+#ifdef MST_STAMPS
+        if (tid == 0 && a.dbg)
+            for (int k = 0; k < 16; ++k) a.dbg[(long)b * 16 + k] = stamp_acc[k];
+#endif
         if (sc[WS_DONE]) return;
         root = sc[WS_NEXT];
         __syncthreads();

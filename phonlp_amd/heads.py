@@ -12,6 +12,8 @@ import torch
 
 from . import ops
 
+import os
+_SKIP_MST = bool(os.environ.get("PHONLP_EXPERIMENT_SKIP_MST"))
 SCORERS = ("unlabeled", "linearization", "distance")
 
 
@@ -141,8 +143,15 @@ class TaskHeads:
         return ops.crf_log_partition(ner_logits.contiguous(), self.w.trans, pm, ln, gd)
 
     # ---- the whole head path for one batch: what annotate() needs per batch (ref :256-287)
-    def annotate_batch(self, enc_dep, sentlens_dep, enc_tag, sentlens_tag, overlap=True) -> Dict[str, torch.Tensor]:
+    def annotate_batch(self, enc_dep, sentlens_dep, enc_tag, sentlens_tag, overlap=True,
+                       join=True) -> Dict[str, torch.Tensor]:
         """Returns device int32 tensors: pos [B,Lt], ner [B,Lt], heads [B,Ld], rels [B,Ld], mst_status [B].
+
+        `join=False` (with `overlap`) is the streaming form for back-to-back batches: the tail of the batch (labels
+        at the decoded heads) is enqueued on a separate finishing stream, returned as out["stream"], and the
+        calling stream is NOT made to wait for the MST -- so the next batch's GEMMs start while this batch's MST is
+        still decoding.  The outputs are then only valid on out["stream"] (enqueue consumers there, or wait on
+        out["done"]).
 
         With `overlap` the three independent chains run on separate HIP streams: the tagger chain (POS head,
         NER emissions, Viterbi) and the MST decode (which only needs the arc log-probs) run beside the label
@@ -160,8 +169,8 @@ class TaskHeads:
         w = self.w
         main = torch.cuda.current_stream()
         if not hasattr(self, "_side"):
-            self._side = (torch.cuda.Stream(), torch.cuda.Stream())
-        s_tag, s_mst = self._side
+            self._side = (torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream())
+        s_tag, s_mst, s_fin = self._side
         lens_d = as_sentlens(sentlens_dep, enc_dep.device)
         lens_t = as_sentlens(sentlens_tag, enc_tag.device)
         start = torch.cuda.Event()
@@ -185,14 +194,31 @@ class TaskHeads:
         s_mst.wait_event(arc_done)
         arc_logp.record_stream(s_mst)
         with torch.cuda.stream(s_mst):
-            heads, status = ops.mst_one_root(arc_logp, lens_d)
+            if _SKIP_MST:  # timing experiment only
+                heads = torch.zeros(arc_logp.shape[:2], dtype=torch.int32, device=arc_logp.device)
+                status = torch.zeros(arc_logp.shape[0], dtype=torch.int32, device=arc_logp.device)
+            else:
+                heads, status = ops.mst_one_root(arc_logp, lens_d)
             mst_done = torch.cuda.Event()
             mst_done.record(s_mst)
         XF, T = ops.label_project(hidden, w.lab_W12, w.lab_b12, w.lab_Wbt, w.H, w.O)
-        main.wait_event(mst_done)
-        main.wait_event(tag_done)
+        if join:
+            fin = main
+        else:
+            fin = s_fin
+            proj_done = torch.cuda.Event()
+            proj_done.record(main)
+            fin.wait_event(proj_done)
+            for t in (XF, T, lens_d, lens_t):
+                t.record_stream(fin)
+        fin.wait_event(mst_done)
+        fin.wait_event(tag_done)
         for t in (heads, status, ner, tag["pos_pred"]):
-            t.record_stream(main)
+            t.record_stream(fin)
         # labels only where annotate() reads them: at the decoded heads (ref annotate_model.py:263-266)
-        rels, _ = ops.label_at_heads(T, XF, heads, lens_d, w.H, w.O)
-        return {"pos": tag["pos_pred"], "ner": ner, "heads": heads, "rels": rels, "mst_status": status}
+        with torch.cuda.stream(fin):
+            rels, _ = ops.label_at_heads(T, XF, heads, lens_d, w.H, w.O)
+            done = torch.cuda.Event()
+            done.record(fin)
+        return {"pos": tag["pos_pred"], "ner": ner, "heads": heads, "rels": rels, "mst_status": status,
+                "stream": fin, "done": done}

@@ -419,6 +419,27 @@ def test_label_at_heads_matches_dense_label_scorer(dev, engine, B, L, H, O):
                 assert abs(float(col[got[b, i]]) - float(col[want[b, i]])) <= tol, (b, i)
 
 
+def test_streaming_batches_match_joined(dev):
+    """annotate_batch(join=False) on back-to-back batches (tails on the finishing stream, next batch's GEMMs not
+    waiting for the MST) gives exactly the outputs of the joined form."""
+    from phonlp_amd import HeadWeights, TaskHeads
+    from phonlp_amd import synthetic as S
+    heads = TaskHeads(HeadWeights.from_state_dict(S.make_state_dict(64, 12, 48, 7, 6, 5, seed=3), dev))
+    batches = []
+    for k in range(4):
+        B, L = 24 + 8 * k, 40 + 7 * k
+        ed, et = S.make_encoder_outputs(B, L, 64, seed=50 + k)
+        lens1 = S.make_sentlens(B, L, ragged=True, seed=k)
+        batches.append((ed.to(dev), lens1, et.to(dev), [n - 1 for n in lens1]))
+    want = [heads.annotate_batch(*b) for b in batches]
+    torch.cuda.synchronize()
+    got = [heads.annotate_batch(*b, join=False) for b in batches]  # enqueued back to back, no host sync between
+    torch.cuda.synchronize()
+    for w, g in zip(want, got):
+        for k in ("pos", "ner", "heads", "rels", "mst_status"):
+            assert torch.equal(w[k].cpu(), g[k].cpu()), k
+
+
 @pytest.mark.parametrize("B,S,L,E,idx_dtype", [(5, 40, 19, 32, torch.int64), (64, 200, 128, 768, torch.int32)])
 def test_gather_first_subword(dev, B, S, L, E, idx_dtype):
     from phonlp_amd import ops

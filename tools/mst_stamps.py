@@ -18,9 +18,11 @@ ops.mst_one_root(arc, lens); torch.cuda.synchronize()
 dbg.zero_()
 ops.mst_one_root(arc, lens); torch.cuda.synchronize()
 d = dbg.cpu().double()
-names = ["init", "argmax", "cycles", "lists", "edge+sum", "enter/leave+rec", "contract", "expand", "oneroot"]
-tot = d[:, :9].sum(1)
+names = ["init", "argmax", "cycles", "lists", "edge+sum", "enter/leave+rec", "contract", "expand", "oneroot", "-", "-", "-", "rescan"]
+tot = d[:, :9].sum(1) + d[:, 12]
+print("rows rescanned per level: %.2f" % (d[:, 13].sum() / max(d[:, 10].sum(), 1)))
 print("runs/sentence mean %.2f max %d; levels/sentence mean %.1f max %d" % (d[:, 11].mean(), d[:, 11].max(), d[:, 10].mean(), d[:, 10].max()))
 print("cycles/sentence mean %.0f max %.0f" % (tot.mean(), tot.max()))
 for k, n in enumerate(names):
+    if n == "-": continue
     print(f"  {n:16s} share {100*d[:,k].sum()/tot.sum():5.1f}%   per level {d[:,k].sum()/max(d[:,10].sum(),1):8.0f} cyc")
