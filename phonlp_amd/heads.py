@@ -12,8 +12,6 @@ import torch
 
 from . import ops
 
-import os
-_SKIP_MST = bool(os.environ.get("PHONLP_EXPERIMENT_SKIP_MST"))
 SCORERS = ("unlabeled", "linearization", "distance")
 
 
@@ -194,11 +192,7 @@ class TaskHeads:
         s_mst.wait_event(arc_done)
         arc_logp.record_stream(s_mst)
         with torch.cuda.stream(s_mst):
-            if _SKIP_MST:  # timing experiment only
-                heads = torch.zeros(arc_logp.shape[:2], dtype=torch.int32, device=arc_logp.device)
-                status = torch.zeros(arc_logp.shape[0], dtype=torch.int32, device=arc_logp.device)
-            else:
-                heads, status = ops.mst_one_root(arc_logp, lens_d)
+            heads, status = ops.mst_one_root(arc_logp, lens_d)
             mst_done = torch.cuda.Event()
             mst_done.record(s_mst)
         XF, T = ops.label_project(hidden, w.lab_W12, w.lab_b12, w.lab_Wbt, w.H, w.O)
