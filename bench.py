@@ -114,7 +114,10 @@ def main():
     gold_ner = torch.randint(0, T, (B, L - 1), generator=g, dtype=torch.int32).to(dev)
     gold_head = torch.randint(0, L, (B, L), generator=g, dtype=torch.int32).to(dev)
     gold_rel = torch.randint(0, O, (B, L), generator=g, dtype=torch.int32).to(dev)
-    counts = torch.zeros(8, dtype=torch.int64, device=dev)
+    counts = torch.zeros(11, dtype=torch.int64, device=dev)  # 8 eval counts + NER entity (correct, predicted, gold)
+    from phonlp_amd.sharding import prf, tag_tables
+    ner_vocab = ["<PAD>", "<UNK>", "<EMPTY>", "<ROOT>", "O", "B-PER", "I-PER", "B-LOC", "I-LOC"][:T]
+    tag_kind, tag_type = (t.to(dev) for t in tag_tables(ner_vocab))
 
     STREAMING = int(os.environ.get("PHONLP_BENCH_STREAMING", "0"))
 
@@ -123,8 +126,9 @@ def main():
         # batch's GEMMs do not wait for this batch's MST; the fence below waits for every stream
         out = heads.annotate_batch(enc_dep, ld, enc_tag, lt, join=STREAMING == 0)
         with torch.cuda.stream(out["stream"]):
-            counts.add_(ops.eval_counts(out["pos"], out["ner"], out["heads"], out["rels"], gold_pos, gold_ner,
-                                        gold_head, gold_rel, lt, ld, out["mst_status"]))
+            counts[:8].add_(ops.eval_counts(out["pos"], out["ner"], out["heads"], out["rels"], gold_pos, gold_ner,
+                                            gold_head, gold_rel, lt, ld, out["mst_status"]))
+            counts[8:].add_(ops.ner_entity_counts(out["ner"], gold_ner, lt, tag_kind, tag_type))
         return out
 
     def fence():
@@ -206,7 +210,9 @@ def main():
                          "algorithmic_flops_per_launch": fl["label_stage_a"] * B},
             "kernels_ms": {k: round(v[1], 4) for k, v in sorted(kt.stats.items())},
             "eval_counts": {"sentences": c[0], "words": c[1], "pos_correct": c[2], "ner_correct": c[3],
-                            "uas_correct": c[4], "las_correct": c[5]},
+                            "uas_correct": c[4], "las_correct": c[5], "ner_entities_correct": c[8],
+                            "ner_entities_predicted": c[9], "ner_entities_gold": c[10],
+                            "ner_entity_prf": [round(v, 4) for v in prf(c[8], c[9], c[10])]},
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(sd, enc_dep_h, enc_tag_h, lens_dep, lens_tag)

@@ -194,6 +194,17 @@ int phonlp_eval_counts(const int32_t *pos, const int32_t *ner, const int32_t *he
                        const int32_t *gold_rel, const int32_t *lens_tag, const int32_t *lens_dep,
                        const int32_t *mst_status, int B, int Lt, int Ld, int64_t *counts, void *stream);
 
+/* Entity-level NER counts -- models/ner/scorer.py:13-57 (score_by_entity) over ner/utils.py:85-128
+ * (decode_from_bioes): counts[0..2] += {predicted entities that are also gold entities (same sentence, first index,
+ * last index and type), predicted entities, gold entities}; precision/recall/F1 follow on the host from the
+ * all-reduced sums.  pred/gold int32 [B,L] tag ids, sentlens int32 [B]; tag_kind int32 [T] = 0 'O', 1 'B-', 2 'I-',
+ * 3 'E-', 4 'S-', any other value for tags the decoder ignores (<PAD>, <UNK>, ...); tag_type int32 [T] = id of the
+ * type string after the prefix.  L <= 4096.
+ */
+int phonlp_ner_entity_counts(const int32_t *pred, const int32_t *gold, const int32_t *sentlens,
+                             const int32_t *tag_kind, const int32_t *tag_type, int B, int L, int T,
+                             int64_t *counts, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Per-kernel timing (no counterpart in the reference, which has no profiling: SURVEY.md section 5).
  * Between _begin and _end every kernel launch of the library is bracketed by a hipEvent pair recorded

@@ -311,3 +311,46 @@ def chuliu_edmonds_one_root(scores: np.ndarray) -> np.ndarray:
     if best_tree is None:
         raise NoFiniteTree()
     return best_tree
+
+
+# ------------------------------------------------------------------------------------------ NER entity scoring
+def decode_from_bioes(tags):
+    """ref models/ner/utils.py:85-128: entities as (first index, last index, type of the last tag) from BIOES tag
+    strings; 'O'/None closes an entity, B-/S- close and open, I-/E- extend (opening one if none is open), any other
+    string (e.g. <PAD>) is ignored."""
+    res, idxs, ctype = [], [], None
+    for i, tag in enumerate(tags):
+        tag = "O" if tag is None else tag
+        if tag == "O":
+            if idxs:
+                res.append((idxs[0], idxs[-1], ctype))
+            idxs = []
+        elif tag.startswith("B-") or tag.startswith("S-"):
+            if idxs:
+                res.append((idxs[0], idxs[-1], ctype))
+            idxs, ctype = [i], tag[2:]
+            if tag.startswith("S-"):
+                res.append((i, i, ctype))
+                idxs = []
+        elif tag.startswith("I-") or tag.startswith("E-"):
+            idxs.append(i)
+            ctype = tag[2:]
+            if tag.startswith("E-"):
+                res.append((idxs[0], idxs[-1], ctype))
+                idxs = []
+    if idxs:
+        res.append((idxs[0], idxs[-1], ctype))
+    return res
+
+
+def ner_entity_counts(pred_seqs, gold_seqs):
+    """ref models/ner/scorer.py:13-57: (correct, guessed, gold) entity counts over parallel lists of tag-string
+    sequences; an entity matches when sentence, first index, last index and type agree."""
+    correct = guessed = gold = 0
+    for p, g in zip(pred_seqs, gold_seqs):
+        ge = set(decode_from_bioes(g))
+        pe = decode_from_bioes(p)
+        gold += len(decode_from_bioes(g))
+        guessed += len(pe)
+        correct += sum(1 for e in pe if e in ge)
+    return correct, guessed, gold

@@ -66,6 +66,64 @@ __global__ __launch_bounds__(256) void eval_counts_kernel(const int32_t *pos, co
     }
 }
 
+// Entity-level NER counts (ref models/ner/scorer.py:13-57 score_by_entity over ner/utils.py:85-128
+// decode_from_bioes): counts[0..2] += {predicted entities also in gold, predicted entities, gold entities}.
+// tag_kind[t]: 0 'O', 1 'B-', 2 'I-', 3 'E-', 4 'S-', anything else = a tag the decoder ignores (<PAD>, <UNK>, ...);
+// tag_type[t]: id of the type string after the prefix.  One wavefront per sentence: the tags are staged in LDS,
+// lane 0 replays the reference's state machine (an entity = first index, last index, type of its LAST tag) over
+// gold -- recording (end, type) at the entity's start index, which is unique per entity -- and then over the
+// prediction, looking each entity up at its start.
+__global__ __launch_bounds__(64) void ner_entity_counts_kernel(const int32_t *pred, const int32_t *gold,
+                                                               const int32_t *sentlens, const int32_t *tag_kind,
+                                                               const int32_t *tag_type, int L, int T,
+                                                               unsigned long long *counts) {
+    extern __shared__ int sm[];
+    int *kp = sm, *kg = sm + L, *ge = sm + 2 * L, *gt = sm + 3 * L;  // packed (kind<<24 | type) per position; gold table
+    const int b = blockIdx.x, lane = threadIdx.x;
+    int len = sentlens[b];
+    if (len > L) len = L;
+    for (int i = lane; i < len; i += 64) {
+        const int tp = pred[(long)b * L + i], tg = gold[(long)b * L + i];
+        kp[i] = (tp >= 0 && tp < T) ? (tag_kind[tp] << 24) | (tag_type[tp] & 0xFFFFFF) : (5 << 24);
+        kg[i] = (tg >= 0 && tg < T) ? (tag_kind[tg] << 24) | (tag_type[tg] & 0xFFFFFF) : (5 << 24);
+        ge[i] = -1;
+        gt[i] = -1;
+    }
+    __syncthreads();
+    if (lane != 0) return;
+    unsigned long long n_correct = 0, n_pred = 0, n_gold = 0;
+    auto scan = [&](const int *tags, auto emit) {
+        int cnt = 0, start = 0, last = 0, ctype = -1;
+        for (int i = 0; i < len; ++i) {
+            const int kind = tags[i] >> 24, ty = tags[i] & 0xFFFFFF;
+            if (kind == 0) {  // O
+                if (cnt) emit(start, last, ctype);
+                cnt = 0;
+            } else if (kind == 1) {  // B-
+                if (cnt) emit(start, last, ctype);
+                cnt = 1; start = last = i; ctype = ty;
+            } else if (kind == 2) {  // I-
+                if (!cnt) start = i;
+                ++cnt; last = i; ctype = ty;
+            } else if (kind == 3) {  // E-
+                if (!cnt) start = i;
+                emit(start, i, ty);
+                cnt = 0;
+            } else if (kind == 4) {  // S-
+                if (cnt) emit(start, last, ctype);
+                emit(i, i, ty);
+                cnt = 0;
+            }
+        }
+        if (cnt) emit(start, last, ctype);
+    };
+    scan(kg, [&](int st, int en, int ty) { ge[st] = en; gt[st] = ty; ++n_gold; });
+    scan(kp, [&](int st, int en, int ty) { ++n_pred; n_correct += (ge[st] == en && gt[st] == ty); });
+    if (n_correct) atomicAdd(&counts[0], n_correct);
+    if (n_pred) atomicAdd(&counts[1], n_pred);
+    if (n_gold) atomicAdd(&counts[2], n_gold);
+}
+
 }  // namespace phonlp
 
 using namespace phonlp;
@@ -102,4 +160,16 @@ extern "C" int phonlp_eval_counts(const int32_t *pos, const int32_t *ner, const 
                        gold_pos, gold_ner, gold_head, gold_rel, lens_tag, lens_dep, mst_status, B, Lt, Ld,
                        (unsigned long long *)counts);
     return check_launch("eval_counts_kernel");
+}
+
+extern "C" int phonlp_ner_entity_counts(const int32_t *pred, const int32_t *gold, const int32_t *sentlens,
+                                        const int32_t *tag_kind, const int32_t *tag_type, int B, int L, int T,
+                                        int64_t *counts, void *stream) {
+    if (!pred || !gold || !sentlens || !tag_kind || !tag_type || !counts || B <= 0 || L <= 0 || T <= 0)
+        return fail(PHONLP_ERR_SHAPE, "ner_entity_counts: bad argument");
+    if ((size_t)L * 4 * sizeof(int) > 64 * 1024) return fail(PHONLP_ERR_UNSUPPORTED, "ner_entity_counts: L > 4096");
+    ProfScope ps("ner_entity_counts", as_stream(stream));
+    hipLaunchKernelGGL(ner_entity_counts_kernel, dim3(B), dim3(64), (size_t)L * 4 * sizeof(int), as_stream(stream), pred,
+                       gold, sentlens, tag_kind, tag_type, L, T, (unsigned long long *)counts);
+    return check_launch("ner_entity_counts_kernel");
 }

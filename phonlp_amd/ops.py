@@ -279,3 +279,21 @@ def eval_counts(pos: Tensor, ner: Tensor, heads: Tensor, rels: Tensor, gold_pos:
                                    _p(gold_rel), _p(lens_tag), _p(lens_dep), _p(mst_status), B, Lt, Ld, _p(counts),
                                    _stream()), "phonlp_eval_counts")
     return counts
+
+
+@torch.library.custom_op("phonlp_amd::ner_entity_counts", mutates_args=())
+def ner_entity_counts(pred: Tensor, gold: Tensor, sentlens: Tensor, tag_kind: Tensor, tag_type: Tensor) -> Tensor:
+    """Entity-level NER counts int64[3] = (correct, predicted, gold) -- ref models/ner/scorer.py score_by_entity.
+    pred/gold int32 [B,L] tag ids; tag_kind/tag_type int32 [T] from sharding.tag_tables()."""
+    for t, n in ((pred, "pred"), (gold, "gold"), (sentlens, "sentlens"), (tag_kind, "tag_kind"), (tag_type, "tag_type")):
+        _need(t, torch.int32, n)
+    B, L = pred.shape
+    counts = torch.zeros(3, dtype=torch.int64, device=pred.device)
+    check(lib().phonlp_ner_entity_counts(_p(pred), _p(gold), _p(sentlens), _p(tag_kind), _p(tag_type), B, L,
+                                         tag_kind.numel(), _p(counts), _stream()), "phonlp_ner_entity_counts")
+    return counts
+
+
+@ner_entity_counts.register_fake
+def _(pred, gold, sentlens, tag_kind, tag_type):
+    return torch.empty(3, dtype=torch.int64, device=pred.device)

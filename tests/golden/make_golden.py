@@ -371,7 +371,50 @@ def gen_joint(name, zero_init):
     save(name, **arrs)
 
 
+# ---------------------------------------------------------------------------- F7 NER entity scoring
+def gen_ner_entities():
+    """Runs the reference's own score_by_entity / decode_from_bioes (models/ner/scorer.py, ner/utils.py) on random
+    tag sequences over a BIOES vocabulary with the four specials, including sequences that are not well formed
+    (I- with no B-, type switches inside an entity, specials in the middle)."""
+    sys.modules.setdefault("gdown", types.ModuleType("gdown"))
+    sys.path.insert(0, REF_ROOT)
+    from phonlp.models.ner import scorer as ref_scorer
+    from phonlp.models.ner.utils import decode_from_bioes as ref_decode
+    vocab = ["<PAD>", "<UNK>", "<EMPTY>", "<ROOT>", "O"] + [f"{p}-{t}" for t in ("PER", "LOC", "ORG") for p in "BIES"]
+    rng = np.random.default_rng(7)
+    arrs = {"vocab": np.asarray(vocab)}
+    n_cases = 6
+    for c in range(n_cases):
+        B, L = int(rng.integers(3, 40)), int(rng.integers(5, 70))
+        lens = rng.integers(1, L + 1, B)
+        lens[0] = L
+        # gold: mostly well formed; pred: gold with noise; case 0 uniform random ids (incl. specials)
+        gold = rng.integers(0, len(vocab), (B, L))
+        if c > 0:
+            gold = np.where(rng.random((B, L)) < 0.5, 4, rng.integers(4 if c > 1 else 0, len(vocab), (B, L)))
+        pred = np.where(rng.random((B, L)) < (0.1 + 0.15 * c), rng.integers(0, len(vocab), (B, L)), gold)
+        gs = [[vocab[t] for t in gold[b, :lens[b]]] for b in range(B)]
+        ps = [[vocab[t] for t in pred[b, :lens[b]]] for b in range(B)]
+        prec, rec, f1 = ref_scorer.score_by_entity(ps, gs, verbose=False)
+        gold_ents = [dict(e, sent_id=i) for i, t in enumerate(gs) for e in ref_decode(t)]
+        pred_ents = [dict(e, sent_id=i) for i, t in enumerate(ps) for e in ref_decode(t)]
+        correct = sum(1 for p_ in pred_ents if p_ in gold_ents)
+        arrs[f"c{c}_pred"], arrs[f"c{c}_gold"], arrs[f"c{c}_lens"] = pred.astype(np.int32), gold.astype(np.int32), lens.astype(np.int32)
+        arrs[f"c{c}_counts"] = np.asarray([correct, len(pred_ents), len(gold_ents)], dtype=np.int64)
+        arrs[f"c{c}_prf"] = np.asarray([prec, rec, f1], dtype=np.float64)
+        # entity lists of the first sentences, flattened (start, end, type index in sorted type names)
+        types_ = sorted({e["type"] for e in pred_ents + gold_ents})
+        arrs[f"c{c}_pred_ents"] = np.asarray([[e["sent_id"], e["start"], e["end"], types_.index(e["type"])] for e in pred_ents],
+                                             dtype=np.int64).reshape(-1, 4)
+        arrs[f"c{c}_types"] = np.asarray(types_)
+    arrs["n_cases"] = np.int64(n_cases)
+    save("ner_entities.npz", **arrs)
+
+
 if __name__ == "__main__":
+    if "--only-ner-entities" in sys.argv:
+        gen_ner_entities()
+        sys.exit(0)
     torch.set_num_threads(4)
     gen_biaffine()
     gen_viterbi()
@@ -379,3 +422,4 @@ if __name__ == "__main__":
     gen_mst()
     gen_joint("joint_small.npz", zero_init=False)
     gen_joint("joint_zero_init.npz", zero_init=True)
+    gen_ner_entities()

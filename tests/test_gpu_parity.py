@@ -472,3 +472,27 @@ def test_eval_counts_vs_python(dev):
     got = ops.eval_counts(d(pos), d(ner), d(heads), d(rels), d(gpos), d(gner), d(ghead), d(grel), d(lens_tag),
                           d(lens_dep), d(status))
     assert got.cpu().tolist() == want.tolist()
+
+
+def test_ner_entity_counts(dev, golden):
+    """Entity-level NER counts kernel: exact against the reference's score_by_entity fixtures, and against the
+    oracle on a headline-sized random batch."""
+    from phonlp_amd import ops
+    from phonlp_amd.sharding import tag_tables
+    z = golden("ner_entities.npz")
+    vocab = [str(v) for v in z["vocab"]]
+    kind, typ = (t.to(dev) for t in tag_tables(vocab))
+    for c in range(int(z["n_cases"])):
+        got = ops.ner_entity_counts(torch.from_numpy(z[f"c{c}_pred"]).to(dev), torch.from_numpy(z[f"c{c}_gold"]).to(dev),
+                                    torch.from_numpy(z[f"c{c}_lens"]).to(dev), kind, typ)
+        assert got.cpu().tolist() == z[f"c{c}_counts"].tolist(), c
+    g = torch.Generator().manual_seed(5)
+    B, L = 256, 127
+    gold = torch.where(torch.rand(B, L, generator=g) < 0.6, torch.tensor(4), torch.randint(0, len(vocab), (B, L), generator=g))
+    pred = torch.where(torch.rand(B, L, generator=g) < 0.2, torch.randint(0, len(vocab), (B, L), generator=g), gold)
+    lens = torch.randint(1, L + 1, (B,), generator=g)
+    got = ops.ner_entity_counts(pred.to(torch.int32).to(dev), gold.to(torch.int32).to(dev), lens.to(torch.int32).to(dev),
+                                kind, typ).cpu().tolist()
+    ps = [[vocab[t] for t in pred[b, :lens[b]].tolist()] for b in range(B)]
+    gs = [[vocab[t] for t in gold[b, :lens[b]].tolist()] for b in range(B)]
+    assert got == list(O.ner_entity_counts(ps, gs))

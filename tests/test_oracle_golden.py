@@ -94,3 +94,24 @@ def test_joint_heads(golden, name):
     loss = O.crf_nll(torch.from_numpy(z["tag_ner_logits"]), torch.from_numpy(z["tag_words_mask"]),
                      torch.from_numpy(z["crf_gold"]), torch.from_numpy(trans))
     assert abs(float(loss) - float(z["crf_loss"])) <= 1e-5 * max(1.0, abs(float(z["crf_loss"])))
+
+
+def test_ner_entity_scoring(golden):
+    """decode_from_bioes / score_by_entity restatement against the reference's own counts and P/R/F1, incl. malformed
+    sequences (I- without B-, type switches, specials inside entities); plus the host-side tag tables."""
+    from phonlp_amd.sharding import prf, tag_tables
+    z = golden("ner_entities.npz")
+    vocab = [str(v) for v in z["vocab"]]
+    kind, typ = tag_tables(vocab)
+    assert kind.tolist()[:5] == [5, 5, 5, 5, 0] and kind.tolist()[5:9] == [1, 2, 3, 4]
+    assert typ.tolist()[5:9] == [0, 0, 0, 0] and typ.tolist()[9] == 1 and typ.tolist()[4] == -1
+    for c in range(int(z["n_cases"])):
+        pred, gold, lens = z[f"c{c}_pred"], z[f"c{c}_gold"], z[f"c{c}_lens"]
+        ps = [[vocab[t] for t in pred[b, :lens[b]]] for b in range(len(lens))]
+        gs = [[vocab[t] for t in gold[b, :lens[b]]] for b in range(len(lens))]
+        counts = O.ner_entity_counts(ps, gs)
+        assert list(counts) == z[f"c{c}_counts"].tolist()
+        np.testing.assert_allclose(prf(*counts), z[f"c{c}_prf"], rtol=0, atol=1e-15)
+        types_ = [str(t) for t in z[f"c{c}_types"]]
+        ents = [[i, st, en, types_.index(ty)] for i, p in enumerate(ps) for st, en, ty in O.decode_from_bioes(p)]
+        assert ents == z[f"c{c}_pred_ents"].tolist()
