@@ -168,6 +168,69 @@ def _annotate(self, text=None, input_file=None, output_file=None, batch_size=1, 
             f.write("\n")
 
 
+# --------------------------------------------------------------------------------------------------- trainer seams
+def _predict_dep(self, batch, unsort=True):
+    """ref models/jointmodel/trainer.py:101-129 (over jointmodel/model.py:162-239 with eval=True): same batch tuple,
+    same return value -- per sentence a list of [head string, deprel string] per word."""
+    tokens, first_subword, orig_idx, sentlens = batch[0], batch[1], batch[6], batch[7]
+    h = self.model._amd_heads
+    with torch.no_grad():
+        dep = h.parser(_encode(self.model, tokens, first_subword), sentlens, want_label_argmax=False)
+        heads, status = ops.mst_one_root(dep["arc_logp"], dep["sentlens"])
+        if int((status != 0).sum().item()):
+            raise AssertionError("chuliu_edmonds_one_root: no finite single-root tree (reference asserts here)")
+        XF, T = ops.label_project(dep["hidden_out"], h.w.lab_W12, h.w.lab_b12, h.w.lab_Wbt, h.w.H, h.w.O)
+        rels, _ = ops.label_at_heads(T, XF, heads, dep["sentlens"], h.w.H, h.w.O)
+    heads, rels = heads.cpu().numpy(), rels.cpu().numpy()
+    pred = [[[str(int(heads[b][j])), r] for j, r in
+             zip(range(1, sentlens[b]), self.vocab["deprel"].unmap(rels[b][1:sentlens[b]]))] for b in range(len(sentlens))]
+    return _unsort(pred, orig_idx) if unsort else pred
+
+
+def _predict_pos(self, batch, unsort=True):
+    """ref trainer.py:131-144 (over jointmodel/model.py:107-137): per sentence a list of [upos string] per word."""
+    tokens, first_subword, orig_idx, sentlens = batch[0], batch[1], batch[3], batch[4]
+    h = self.model._amd_heads
+    with torch.no_grad():
+        enc = _encode(self.model, tokens, first_subword)
+        lens = as_sentlens(sentlens, enc.device)
+        _, pos, _ = ops.pos_head(enc, lens, h.w.upos_hid_w, h.w.upos_hid_b, h.w.upos_clf_w, h.w.upos_clf_b, h.w.emb_ner)
+    pos = pos.cpu().numpy()
+    pred = [[[u] for u in self.vocab["upos"].unmap(pos[b][:sentlens[b]])] for b in range(len(sentlens))]
+    return _unsort(pred, orig_idx) if unsort else pred
+
+
+def _predict_ner(self, batch, unsort=True):
+    """ref trainer.py:146-166 (over jointmodel/model.py:139-160 + crf.py:103-126): per sentence a list of tag strings."""
+    tokens, first_subword, orig_idx, sentlens = batch[0], batch[1], batch[4], batch[5]
+    h = self.model._amd_heads
+    with torch.no_grad():
+        tag = h.tagger(_encode(self.model, tokens, first_subword), sentlens)
+        ner, _ = ops.crf_viterbi(tag["ner_logits"], h.w.trans, tag["sentlens"])
+    ner = ner.cpu().numpy()
+    pred = [self.vocab["ner_tag"].unmap(ner[b][:sentlens[b]]) for b in range(len(sentlens))]
+    return _unsort(pred, orig_idx) if unsort else pred
+
+
+def patch_trainer(trainer, device=None, move_encoder=True):
+    """The evaluation-loop twin of patch(): rebinds `predict_dep`, `predict_pos` and `predict_ner` of a reference
+    `JointTrainer` (models/jointmodel/trainer.py) so that the dev/test scoring loops of the training script run the
+    heads and decoders on the MI355X.  `trainer.model` (jointmodel/model.py JointModel) keeps its encoder and its
+    training-mode forward; only the eval-mode seams change."""
+    dev = device or _dev()
+    model = trainer.model
+    if move_encoder:
+        model.phobert.to(dev)
+    sd = {k: v for k, v in model.state_dict().items() if not k.startswith("phobert.")}
+    weights = HeadWeights.from_state_dict(sd, dev, linearization=bool(model.args.get("linearization", True)),
+                                          distance=bool(model.args.get("distance", True)))
+    model._amd_heads = TaskHeads(weights)
+    trainer.predict_dep = types.MethodType(_predict_dep, trainer)
+    trainer.predict_pos = types.MethodType(_predict_pos, trainer)
+    trainer.predict_ner = types.MethodType(_predict_ner, trainer)
+    return trainer
+
+
 def _unsort(items, original_index):
     """Inverse of the reference's descending-length sort (ref models/common/utils.py:189-195)."""
     assert len(items) == len(original_index), "Number of list elements must match with original indices."

@@ -371,6 +371,58 @@ def gen_joint(name, zero_init):
     save(name, **arrs)
 
 
+# ---------------------------------------------------------------------------- F8 training-side predict_* seams
+def gen_trainer():
+    """JointTrainer.predict_dep / predict_pos / predict_ner of the reference (models/jointmodel/trainer.py:101-166 over
+    jointmodel/model.py eval paths) on one ragged batch each: the evaluation-loop twins of annotate()."""
+    import tempfile
+    amodel = build_joint_model(seed=707)
+    from phonlp.models.jointmodel.trainer import JointTrainer
+    with tempfile.TemporaryDirectory() as td:
+        amodel.phobert.save_pretrained(td)
+        args = dict(amodel.args, pretrained_lm=td)
+        trainer = JointTrainer(args=args, vocab=amodel.vocab, config_phobert=amodel.phobert.config, use_cuda=False)
+    missing, unexpected = trainer.model.load_state_dict(amodel.state_dict(), strict=False)
+    assert not unexpected and all(m.startswith("drop_replacement") for m in missing), (missing, unexpected)
+    trainer.model.eval()
+    with open(os.path.join(REF, "sample_data", "input.txt")) as f:
+        lines = [ln.strip() for ln in f if ln.strip()]
+    sents = [ln.split(" ") for ln in lines[20:31]] + [["x"], ["y", "z", "w"]]
+    arrs = {f"p_{k}": v for k, v in head_state(amodel).items()}
+    for k, v in amodel.state_dict().items():
+        if k.startswith("phobert."):
+            arrs[f"enc_{k}"] = v.detach().numpy()
+    arrs["sent_text"] = np.asarray([" ".join(s_) for s_ in sents])
+    data_t = amodel.chunk_batches(amodel.process_data_tagger(batch_text=sents), len(sents))
+    data_p = amodel.chunk_batches(amodel.process_data_parser(batch_text=sents), len(sents))
+    tok, fsw, wmask, nw, oidx, lens = amodel.get_batch(0, data_t)
+    tok1, fsw1, wmask1, nw1, oidx1, lens1 = amodel.get_batch(0, data_p)
+    g = torch.Generator().manual_seed(9)
+    gold_head = torch.randint(0, 3, (len(lens1), max(lens1) - 1), generator=g)
+    gold_rel = torch.randint(0, len(amodel.vocab["deprel"]), gold_head.shape, generator=g)
+    gold_upos = torch.randint(0, len(amodel.vocab["upos"]), (len(lens), max(lens)), generator=g)
+    gold_ner = torch.randint(0, len(amodel.vocab["ner_tag"]), gold_upos.shape, generator=g)
+    dep_batch = (tok1, fsw1, wmask1, gold_head, gold_rel, nw1, oidx1, lens1)
+    pos_batch = (tok, fsw, gold_upos, oidx, lens)
+    ner_batch = (tok, fsw, wmask, gold_ner, oidx, lens)
+    with torch.no_grad():
+        for unsort in (True, False):
+            tag = "u" if unsort else "s"
+            dep = trainer.predict_dep(dep_batch, unsort=unsort)
+            pos = trainer.predict_pos(pos_batch, unsort=unsort)
+            ner = trainer.predict_ner(ner_batch, unsort=unsort)
+            arrs[f"dep_{tag}"] = np.asarray(["|".join(h + ":" + r for h, r in sent) for sent in dep])
+            arrs[f"pos_{tag}"] = np.asarray(["|".join(w[0] for w in sent) for sent in pos])
+            arrs[f"ner_{tag}"] = np.asarray(["|".join(sent) for sent in ner])
+    for name, t in (("dep_tokens", tok1), ("dep_first", fsw1), ("dep_mask", wmask1), ("dep_gold_head", gold_head),
+                    ("dep_gold_rel", gold_rel), ("tag_tokens", tok), ("tag_first", fsw), ("tag_mask", wmask),
+                    ("gold_upos", gold_upos), ("gold_ner", gold_ner)):
+        arrs[name] = t.numpy()
+    arrs["dep_nwords"], arrs["dep_oidx"], arrs["dep_lens"] = np.int64(nw1), np.asarray(oidx1), np.asarray(lens1)
+    arrs["tag_oidx"], arrs["tag_lens"] = np.asarray(oidx), np.asarray(lens)
+    save("trainer_small.npz", **arrs)
+
+
 # ---------------------------------------------------------------------------- F7 NER entity scoring
 def gen_ner_entities():
     """Runs the reference's own score_by_entity / decode_from_bioes (models/ner/scorer.py, ner/utils.py) on random
@@ -415,6 +467,9 @@ if __name__ == "__main__":
     if "--only-ner-entities" in sys.argv:
         gen_ner_entities()
         sys.exit(0)
+    if "--only-trainer" in sys.argv:
+        gen_trainer()
+        sys.exit(0)
     torch.set_num_threads(4)
     gen_biaffine()
     gen_viterbi()
@@ -423,3 +478,4 @@ if __name__ == "__main__":
     gen_joint("joint_small.npz", zero_init=False)
     gen_joint("joint_zero_init.npz", zero_init=True)
     gen_ner_entities()
+    gen_trainer()

@@ -116,3 +116,60 @@ def test_free_functions(golden):
     out = sc(hd, hd)
     assert tuple(out.shape) == tuple(b["db1_out"].shape)
     np.testing.assert_allclose(out.cpu().numpy(), b["db1_out"], rtol=1e-4, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------ trainer seams
+class _StubTrainer:
+    """Stand-in for the reference's JointTrainer (models/jointmodel/trainer.py): what patch_trainer() touches."""
+
+    def __init__(self, model):
+        self.model, self.vocab, self.use_cuda = model, model.vocab, True
+
+
+def test_patch_trainer_predict_matches_reference(golden):
+    """predict_dep / predict_pos / predict_ner of a patched trainer against the strings the reference's own
+    JointTrainer produced on the same batches (tests/golden/trainer_small.npz), sorted and unsorted."""
+    from phonlp_amd.compat import patch_trainer
+    from tests.stub_model import StubJointModel
+    z = golden("trainer_small.npz")
+    trainer = patch_trainer(_StubTrainer(StubJointModel(z)), move_encoder=False)
+    T = lambda k: torch.from_numpy(z[k])
+    dep_batch = (T("dep_tokens"), T("dep_first"), T("dep_mask"), T("dep_gold_head"), T("dep_gold_rel"),
+                 int(z["dep_nwords"]), z["dep_oidx"].tolist(), z["dep_lens"].tolist())
+    pos_batch = (T("tag_tokens"), T("tag_first"), T("gold_upos"), z["tag_oidx"].tolist(), z["tag_lens"].tolist())
+    ner_batch = (T("tag_tokens"), T("tag_first"), T("tag_mask"), T("gold_ner"), z["tag_oidx"].tolist(),
+                 z["tag_lens"].tolist())
+    for unsort, tag in ((True, "u"), (False, "s")):
+        dep = trainer.predict_dep(dep_batch, unsort=unsort)
+        pos = trainer.predict_pos(pos_batch, unsort=unsort)
+        ner = trainer.predict_ner(ner_batch, unsort=unsort)
+        assert ["|".join(h + ":" + r for h, r in s) for s in dep] == z[f"dep_{tag}"].tolist()
+        assert ["|".join(w[0] for w in s) for s in pos] == z[f"pos_{tag}"].tolist()
+        got_ner, want_ner = ["|".join(s) for s in ner], z[f"ner_{tag}"].tolist()
+        if got_ner != want_ner:
+            # ReLU'd emissions of this tiny random model hold many exact zeros, so distinct tag paths can score
+            # within fp32 rounding of each other; the decoder itself is bit-exact on identical logits
+            # (test_gpu_parity.py).  A differing sentence must be such a near-tie under the CPU oracle's logits.
+            from oracle import heads_oracle as O
+            model = trainer.model
+            sd = {k: v for k, v in model.state_dict().items() if not k.startswith("phobert.")}
+            with torch.no_grad():
+                emb = model.phobert(T("tag_tokens"))[2][-1]
+            enc = torch.stack([emb[i].index_select(0, T("tag_first")[i]) for i in range(emb.size(0))])
+            lens = z["tag_lens"].tolist()
+            logits = O.tagger_heads(enc, lens, sd)["ner_logits"].numpy()
+            trans = sd["crit_ner._transitions"].numpy()
+            order = z["tag_oidx"].tolist()
+            rows = {k: b for b, k in enumerate(order)} if unsort else {b: b for b in range(len(lens))}
+            ids = model.vocab["ner_tag"].index
+
+            def path_score(b, tags):
+                t = [ids[x] for x in tags.split("|")]
+                return sum(float(logits[b, i, t[i]]) for i in range(len(t))) + sum(float(trans[t[i - 1], t[i]]) for i in range(1, len(t)))
+            n_diff = 0
+            for k, (g_, w_) in enumerate(zip(got_ner, want_ner)):
+                if g_ != w_:
+                    n_diff += 1
+                    b = rows[k]
+                    assert abs(path_score(b, g_) - path_score(b, w_)) <= 1e-4 * max(1.0, abs(path_score(b, w_))), (k, g_, w_)
+            assert n_diff <= 2
