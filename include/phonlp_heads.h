@@ -112,11 +112,18 @@ int phonlp_dep_hidden(const float *feat, int D, const int32_t *sentlens, int B, 
  * one can be disabled with use_lin/use_dist = 0 but the pack keeps its slot).
  * W12 [n_scorers*2*KP, D], b12 [n_scorers*2*KP], Wbt [n_scorers*KP, KP] from the pack calls.
  * arc_logp [B,L,L].  raw_opt: NULL or [3,B,L,L] receiving the raw scorer outputs.
+ *
+ * Folded form (pad_sentlens and b12_pad both non-NULL; both NULL otherwise): `hidden` holds the rows BEFORE dep_hid
+ * (feat = [x ; pos_emb]; padded rows may hold anything) and W12/b12 were packed from W1.Wdep, W1.bdep + b1 (resp.
+ * W2): one GEMM instead of annotate_model.py:186-187 followed by biaffine.py:82-85's first layer.  Rows at or beyond
+ * pad_sentlens[b] are written as relu(b12_pad) -- b12_pad is the pack of the ORIGINAL biases -- which is what the
+ * reference's scorers make of pad_packed_sequence's all-zero hidden rows.  Same convention for the label entries.
  */
 size_t phonlp_biaffine_arc_ws_bytes(int B, int L, int H, int n_scorers);
 int phonlp_deep_biaffine_arc(const float *hidden, int D, int B, int L, int H, int n_scorers, int use_lin, int use_dist,
                              const float *W12, const float *b12, const float *Wbt,
-                             float *arc_logp, float *raw_opt, void *ws, size_t ws_bytes, void *stream);
+                             float *arc_logp, float *raw_opt, void *ws, size_t ws_bytes, void *stream,
+                             const int32_t *pad_sentlens, const float *b12_pad);
 
 /* ------------------------------------------------------------------------------------------
  * Label scores -- annotate_model.py:190,215 (deprel DeepBiaffineScorer + .max(3)[1]):
@@ -127,7 +134,8 @@ int phonlp_deep_biaffine_arc(const float *hidden, int D, int B, int L, int H, in
 size_t phonlp_biaffine_label_ws_bytes(int B, int L, int H, int O);
 int phonlp_deep_biaffine_label(const float *hidden, int D, int B, int L, int H, int O,
                                const float *W12, const float *b12, const float *Wbt,
-                               int32_t *label_argmax, float *scores_opt, void *ws, size_t ws_bytes, void *stream);
+                               int32_t *label_argmax, float *scores_opt, void *ws, size_t ws_bytes, void *stream,
+                               const int32_t *pad_sentlens, const float *b12_pad);
 
 /* The same scorer cut at the MST, for annotate(): the reference computes the whole label tensor
  * (annotate_model.py:190,215) but reads it only at j = heads[b,i] (annotate_model.py:263-266:
@@ -139,7 +147,8 @@ int phonlp_deep_biaffine_label(const float *hidden, int D, int B, int L, int H, 
  * contraction.  best_opt: NULL or [B*L] receiving the winning score.
  */
 int phonlp_label_project(const float *hidden, int D, int B, int L, int H, int O,
-                         const float *W12, const float *b12, const float *Wbt, float *XF, float *T, void *stream);
+                         const float *W12, const float *b12, const float *Wbt, float *XF, float *T, void *stream,
+                         const int32_t *pad_sentlens, const float *b12_pad);
 int phonlp_label_at_heads(const float *T, const float *XF, const int32_t *heads, const int32_t *sentlens,
                           int B, int L, int H, int O, int32_t *rels, float *best_opt, void *stream);
 

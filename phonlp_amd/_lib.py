@@ -23,15 +23,15 @@ SIGNATURES = {
     "phonlp_ner_emission": (_i, [_p, _i, _p, _i, _i, _p, _p, _i, _p, _p]),
     "phonlp_dep_hidden": (_i, [_p, _i, _p, _i, _i, _p, _p, _p, _p]),
     "phonlp_biaffine_arc_ws_bytes": (_z, [_i, _i, _i, _i]),
-    "phonlp_deep_biaffine_arc": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _z, _p]),
+    "phonlp_deep_biaffine_arc": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _z, _p, _p, _p]),
     "phonlp_biaffine_label_ws_bytes": (_z, [_i, _i, _i, _i]),
-    "phonlp_deep_biaffine_label": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _z, _p]),
+    "phonlp_deep_biaffine_label": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _z, _p, _p, _p]),
     "phonlp_crf_viterbi": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _p]),
     "phonlp_crf_log_partition": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p]),
     "phonlp_mst_ws_bytes": (_z, [_i, _i]),
     "phonlp_mst_one_root": (_i, [_p, _p, _i, _i, _p, _p, _p, _z, _p]),
     "phonlp_ner_entity_counts": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p, _p]),
-    "phonlp_label_project": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p]),
+    "phonlp_label_project": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "phonlp_label_at_heads": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p]),
     "phonlp_gather_labels": (_i, [_p, _p, _p, _i, _i, _p, _p]),
     "phonlp_gather_first_subword": (_i, [_p, _p, _i, _p, _i, _i, _i, _i, _p, _p]),

@@ -13,7 +13,7 @@ namespace phonlp {
 
 int gemm_engine();
 int launch_linear(const char *tag, const float *X, long ldx, const float *W, long ldw, const float *bias, float *Y, long ldy, int M,
-                  int N, int K, int relu, const int32_t *sentlens, int L, hipStream_t stream);
+                  int N, int K, int relu, const int32_t *sentlens, int L, hipStream_t stream, const float *pad_bias = nullptr);
 
 // ------------------------------------------------------------------------------------------ arc
 struct ArcArgs {
@@ -344,7 +344,8 @@ extern "C" size_t phonlp_biaffine_arc_ws_bytes(int B, int L, int H, int n_scorer
 
 extern "C" int phonlp_deep_biaffine_arc(const float *hidden, int D, int B, int L, int H, int n_scorers, int use_lin,
                                         int use_dist, const float *W12, const float *b12, const float *Wbt,
-                                        float *arc_logp, float *raw_opt, void *ws, size_t ws_bytes, void *stream) {
+                                        float *arc_logp, float *raw_opt, void *ws, size_t ws_bytes, void *stream,
+                                        const int32_t *pad_sentlens, const float *b12_pad) {
     if (!hidden || !W12 || !b12 || !Wbt || !arc_logp || B <= 0 || L <= 0 || H <= 0 || D <= 0)
         return fail(PHONLP_ERR_SHAPE, "deep_biaffine_arc: bad argument");
     if (n_scorers != 1 && n_scorers != 3) return fail(PHONLP_ERR_SHAPE, "deep_biaffine_arc: n_scorers must be 1 or 3");
@@ -357,7 +358,10 @@ extern "C" int phonlp_deep_biaffine_arc(const float *hidden, int D, int B, int L
     const int M = B * L, KP = kp_of(H), S = n_scorers;
     float *XF = (float *)ws;
     float *T = (float *)((char *)ws + align_up((size_t)M * S * 2 * KP * sizeof(float), 256));
-    int rc = launch_linear("linear:arc_w12", hidden, D, W12, D, b12, XF, (long)S * 2 * KP, M, S * 2 * KP, D, 1, nullptr, 0, st);
+    if ((pad_sentlens == nullptr) != (b12_pad == nullptr))
+        return fail(PHONLP_ERR_SHAPE, "deep_biaffine_arc: pad_sentlens and b12_pad go together");
+    int rc = launch_linear("linear:arc_w12", hidden, D, W12, D, b12, XF, (long)S * 2 * KP, M, S * 2 * KP, D, 1, pad_sentlens,
+                           pad_sentlens ? L : 0, st, b12_pad);
     if (rc) return rc;
     for (int s = 0; s < S; ++s) {
         rc = launch_linear("linear:arc_stage_a", XF + 2 * s * KP, (long)S * 2 * KP, Wbt + (long)s * KP * KP, KP, nullptr, T + s * KP,
@@ -389,7 +393,8 @@ extern "C" size_t phonlp_biaffine_label_ws_bytes(int B, int L, int H, int O) {
 
 extern "C" int phonlp_deep_biaffine_label(const float *hidden, int D, int B, int L, int H, int O, const float *W12,
                                           const float *b12, const float *Wbt, int32_t *label_argmax,
-                                          float *scores_opt, void *ws, size_t ws_bytes, void *stream) {
+                                          float *scores_opt, void *ws, size_t ws_bytes, void *stream,
+                                          const int32_t *pad_sentlens, const float *b12_pad) {
     if (!hidden || !W12 || !b12 || !Wbt || !label_argmax || B <= 0 || L <= 0 || H <= 0 || D <= 0 || O <= 0)
         return fail(PHONLP_ERR_SHAPE, "deep_biaffine_label: bad argument");
     if (ws_bytes < phonlp_biaffine_label_ws_bytes(B, L, H, O) || !ws)
@@ -398,7 +403,10 @@ extern "C" int phonlp_deep_biaffine_label(const float *hidden, int D, int B, int
     const int M = B * L, KP = kp_of(H);
     float *XF = (float *)ws;
     float *T = (float *)((char *)ws + align_up((size_t)M * 2 * KP * sizeof(float), 256));
-    int rc = launch_linear("linear:label_w12", hidden, D, W12, D, b12, XF, 2L * KP, M, 2 * KP, D, 1, nullptr, 0, st);
+    if ((pad_sentlens == nullptr) != (b12_pad == nullptr))
+        return fail(PHONLP_ERR_SHAPE, "deep_biaffine_label: pad_sentlens and b12_pad go together");
+    int rc = launch_linear("linear:label_w12", hidden, D, W12, D, b12, XF, 2L * KP, M, 2 * KP, D, 1, pad_sentlens,
+                           pad_sentlens ? L : 0, st, b12_pad);
     if (rc) return rc;
     rc = launch_linear("linear:label_stage_a", XF, 2L * KP, Wbt, KP, nullptr, T, (long)O * KP, M, O * KP, KP, 0, nullptr, 0, st);
     if (rc) return rc;
@@ -410,12 +418,16 @@ extern "C" int phonlp_deep_biaffine_label(const float *hidden, int D, int B, int
 }
 
 extern "C" int phonlp_label_project(const float *hidden, int D, int B, int L, int H, int O, const float *W12,
-                                    const float *b12, const float *Wbt, float *XF, float *T, void *stream) {
+                                    const float *b12, const float *Wbt, float *XF, float *T, void *stream,
+                                    const int32_t *pad_sentlens, const float *b12_pad) {
     if (!hidden || !W12 || !b12 || !Wbt || !XF || !T || B <= 0 || L <= 0 || H <= 0 || D <= 0 || O <= 0)
         return fail(PHONLP_ERR_SHAPE, "label_project: bad argument");
     hipStream_t st = as_stream(stream);
     const int M = B * L, KP = kp_of(H);
-    int rc = launch_linear("linear:label_w12", hidden, D, W12, D, b12, XF, 2L * KP, M, 2 * KP, D, 1, nullptr, 0, st);
+    if ((pad_sentlens == nullptr) != (b12_pad == nullptr))
+        return fail(PHONLP_ERR_SHAPE, "label_project: pad_sentlens and b12_pad go together");
+    int rc = launch_linear("linear:label_w12", hidden, D, W12, D, b12, XF, 2L * KP, M, 2 * KP, D, 1, pad_sentlens,
+                           pad_sentlens ? L : 0, st, b12_pad);
     if (rc) return rc;
     return launch_linear("linear:label_stage_a", XF, 2L * KP, Wbt, KP, nullptr, T, (long)O * KP, M, O * KP, KP, 0, nullptr, 0, st);
 }

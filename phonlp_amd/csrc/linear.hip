@@ -13,6 +13,7 @@ struct LinearArgs {
     const float *X;
     const float *W;
     const float *bias;
+    const float *pad_bias;  // NULL: padded rows are written as zeros; else as act(pad_bias) (see launch_linear)
     float *Y;
     const int32_t *sentlens;
     long ldx, ldw, ldy;
@@ -43,6 +44,14 @@ __device__ __forceinline__ void linear_epilogue(f32x16 (&acc)[TM][TN], float *ld
                 if (col + 2 < a.N) bv.z = a.bias[col + 2];
                 if (col + 3 < a.N) bv.w = a.bias[col + 3];
             }
+            float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);  // value of a padded row
+            if (a.pad_bias) {
+                if (col < a.N) pv.x = a.pad_bias[col];
+                if (col + 1 < a.N) pv.y = a.pad_bias[col + 1];
+                if (col + 2 < a.N) pv.z = a.pad_bias[col + 2];
+                if (col + 3 < a.N) pv.w = a.pad_bias[col + 3];
+                if (a.relu) { pv.x = fmaxf(pv.x, 0.f); pv.y = fmaxf(pv.y, 0.f); pv.z = fmaxf(pv.z, 0.f); pv.w = fmaxf(pv.w, 0.f); }
+            }
             unsigned live[TM];
     #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -70,7 +79,7 @@ __device__ __forceinline__ void linear_epilogue(f32x16 (&acc)[TM][TN], float *ld
                     float4 v = *reinterpret_cast<const float4 *>(ep + lrow * EP + c4);
                     v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
                     if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                    if (!((live[i] >> it) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (!((live[i] >> it) & 1u)) v = pv;
                     if (row >= a.M || col >= a.N) continue;
                     float *y = a.Y + (long)row * a.ldy + col;
                     if (vec_ok) {
@@ -832,13 +841,17 @@ static int persistent_grid(int ntiles) {
     return 512;
 }
 
+// `sentlens` (with L) marks the padded rows (row % L >= sentlens[row / L]).  They are written as zeros -- or, when
+// `pad_bias` is given, as act(pad_bias): that is what a following layer makes of an all-zero input row, used when
+// the layer that produced those zero rows has been folded into this one (heads.py: dep_hid folded into W1/W2).
 int launch_linear(const char *tag, const float *X, long ldx, const float *W, long ldw, const float *bias, float *Y, long ldy, int M,
-                  int N, int K, int relu, const int32_t *sentlens, int L, hipStream_t stream) {
+                  int N, int K, int relu, const int32_t *sentlens, int L, hipStream_t stream, const float *pad_bias) {
     if (!X || !W || !Y || M <= 0 || N <= 0 || K <= 0) return fail(PHONLP_ERR_SHAPE, "linear: bad argument");
     if ((K & 3) || (ldx & 3) || (ldw & 3) || ((uintptr_t)X & 15) || ((uintptr_t)W & 15))
         return fail(PHONLP_ERR_SHAPE, "linear: K, ldx, ldw must be multiples of 4 and X, W 16-byte aligned");
     if (sentlens && L <= 0) return fail(PHONLP_ERR_SHAPE, "linear: sentlens given but L <= 0");
-    LinearArgs a{X, W, bias, Y, sentlens, ldx, ldw, ldy, M, N, K, L, relu, 0, 0};
+    if (pad_bias && !sentlens) return fail(PHONLP_ERR_SHAPE, "linear: pad_bias needs sentlens");
+    LinearArgs a{X, W, bias, pad_bias, Y, sentlens, ldx, ldw, ldy, M, N, K, L, relu, 0, 0};
     const bool stage_a = tag && !strcmp(tag, "linear:label_stage_a");
     ProfScope ps(tag, stream);
     a.num_m = ceil_div(M, 128);
@@ -932,7 +945,7 @@ extern "C" int phonlp_get_gemm_engine(void) { return gemm_engine(); }
 
 extern "C" int phonlp_linear(const float *X, int ldx, const float *W, int ldw, const float *bias, float *Y, int ldy,
                              int M, int N, int K, int relu, const int32_t *sentlens, int L, void *stream) {
-    return launch_linear("linear", X, ldx, W, ldw, bias, Y, ldy, M, N, K, relu, sentlens, L, as_stream(stream));
+    return launch_linear("linear", X, ldx, W, ldw, bias, Y, ldy, M, N, K, relu, sentlens, L, as_stream(stream), nullptr);
 }
 
 extern "C" int phonlp_pack_scorer_linear(const float *W1, const float *b1, const float *W2, const float *b2, int H,

@@ -41,6 +41,11 @@ class HeadWeights:
     lab_W12: torch.Tensor
     lab_b12: torch.Tensor
     lab_Wbt: torch.Tensor
+    # dep_hid folded into the scorers' first layer (W1.Wdep, W1.bdep + b1; same for W2), used by annotate_batch
+    arc_W12f: torch.Tensor
+    arc_b12f: torch.Tensor
+    lab_W12f: torch.Tensor
+    lab_b12f: torch.Tensor
     H: int
     O: int
     n_arc_scorers: int
@@ -58,22 +63,43 @@ class HeadWeights:
             return ops.pack_scorer(g(f"{name}.W1.weight"), g(f"{name}.W1.bias"), g(f"{name}.W2.weight"),
                                    g(f"{name}.W2.bias"), g(f"{name}.scorer.W_bilin.weight"))
 
+        # dep_hid (ref annotate_model.py:186-187) has no activation, so it folds into the first layer of every
+        # scorer: relu(W1 (Wd x + bd) + b1) = relu((W1 Wd) x + (W1 bd + b1)).  The products are formed once in
+        # float64 and rounded to fp32 (one rounding per weight, like any stored fp32 weight).
+        Wd64, bd64 = sd["dep_hid.weight"].detach().double().cpu(), sd["dep_hid.bias"].detach().double().cpu()
+
+        def fold(w_name, b_name):
+            W, b = sd[w_name].detach().double().cpu(), sd[b_name].detach().double().cpu()
+            return ((W @ Wd64).to(device=device, dtype=torch.float32).contiguous(),
+                    (W @ bd64 + b).to(device=device, dtype=torch.float32).contiguous())
+
+        def pack_folded(name):
+            W1, b1 = fold(f"{name}.W1.weight", f"{name}.W1.bias")
+            W2, b2 = fold(f"{name}.W2.weight", f"{name}.W2.bias")
+            return ops.pack_scorer(W1, b1, W2, b2, g(f"{name}.scorer.W_bilin.weight"))[:2]
+
         H = sd["unlabeled.W1.weight"].shape[0]
         O = sd["deprel.scorer.W_bilin.weight"].shape[2]
         if linearization or distance:
             # the arc kernel keeps one slot per scorer; a disabled scorer gets zero weights and is ignored
             packs = []
+            fpacks = []
             for name, on in zip(SCORERS, (True, linearization, distance)):
                 if on:
                     packs.append(pack(name))
+                    fpacks.append(pack_folded(name))
                 else:
                     packs.append(tuple(torch.zeros_like(t) for t in packs[0]))
+                    fpacks.append(tuple(torch.zeros_like(t) for t in fpacks[0]))
             arc = tuple(torch.cat([p[k] for p in packs], 0).contiguous() for k in range(3))
+            arcf = tuple(torch.cat([p[k] for p in fpacks], 0).contiguous() for k in range(2))
             n_arc = 3
         else:
             arc = pack("unlabeled")
+            arcf = pack_folded("unlabeled")
             n_arc = 1
         lab = pack("deprel")
+        labf = pack_folded("deprel")
         return cls(
             upos_hid_w=g("upos_hid.weight"), upos_hid_b=g("upos_hid.bias"),
             upos_clf_w=g("upos_clf.weight"), upos_clf_b=g("upos_clf.bias"),
@@ -83,6 +109,7 @@ class HeadWeights:
             dep_hid_w=g("dep_hid.weight"), dep_hid_b=g("dep_hid.bias"),
             arc_W12=arc[0], arc_b12=arc[1], arc_Wbt=arc[2],
             lab_W12=lab[0], lab_b12=lab[1], lab_Wbt=lab[2],
+            arc_W12f=arcf[0], arc_b12f=arcf[1], lab_W12f=labf[0], lab_b12f=labf[1],
             H=H, O=O, n_arc_scorers=n_arc, linearization=bool(linearization), distance=bool(distance),
         )
 
@@ -183,9 +210,9 @@ class TaskHeads:
         # parser chain up to the arc log-probs on the main stream
         feat, _, _ = ops.pos_head(enc_dep.contiguous(), lens_d, w.upos_hid_w, w.upos_hid_b, w.upos_clf_w,
                                   w.upos_clf_b, w.emb_dep)
-        hidden = ops.dep_hidden(feat, lens_d, w.dep_hid_w, w.dep_hid_b)
-        arc_logp, _ = ops.deep_biaffine_arc(hidden, w.arc_W12, w.arc_b12, w.arc_Wbt, w.H, w.n_arc_scorers,
-                                            w.linearization, w.distance, False)
+        # dep_hid is folded into the scorers' first layers (HeadWeights.from_state_dict): the scorers read `feat`
+        arc_logp, _ = ops.deep_biaffine_arc(feat, w.arc_W12f, w.arc_b12f, w.arc_Wbt, w.H, w.n_arc_scorers,
+                                            w.linearization, w.distance, False, lens_d, w.arc_b12)
         arc_done = torch.cuda.Event()
         arc_done.record(main)
         # MST beside the label scorer
@@ -195,7 +222,7 @@ class TaskHeads:
             heads, status = ops.mst_one_root(arc_logp, lens_d)
             mst_done = torch.cuda.Event()
             mst_done.record(s_mst)
-        XF, T = ops.label_project(hidden, w.lab_W12, w.lab_b12, w.lab_Wbt, w.H, w.O)
+        XF, T = ops.label_project(feat, w.lab_W12f, w.lab_b12f, w.lab_Wbt, w.H, w.O, lens_d, w.lab_b12)
         if join:
             fin = main
         else:

@@ -124,7 +124,8 @@ def dep_hidden(feat: Tensor, sentlens: Tensor, Wdep: Tensor, bdep: Tensor) -> Te
 
 @torch.library.custom_op("phonlp_amd::deep_biaffine_arc", mutates_args=())
 def deep_biaffine_arc(hidden: Tensor, W12: Tensor, b12: Tensor, Wbt: Tensor, H: int, n_scorers: int, use_lin: bool,
-                      use_dist: bool, want_raw: bool) -> Tuple[Tensor, Tensor]:
+                      use_dist: bool, want_raw: bool,
+                      pad_sentlens: Optional[Tensor] = None, b12_pad: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
     """hidden [B,L,D] -> (arc log-probs [B,L,L], raw scorer outputs [3,B,L,L] or an empty tensor)."""
     _need(hidden, torch.float32, "hidden")
     B, L, D = hidden.shape
@@ -135,13 +136,14 @@ def deep_biaffine_arc(hidden: Tensor, W12: Tensor, b12: Tensor, Wbt: Tensor, H: 
     ws = _ws(nb, dev)
     check(lib().phonlp_deep_biaffine_arc(_p(hidden), D, B, L, H, n_scorers, int(use_lin), int(use_dist), _p(W12),
                                          _p(b12), _p(Wbt), _p(out), _p(raw) if want_raw else None, _p(ws), nb,
-                                         _stream()), "phonlp_deep_biaffine_arc")
+                                         _stream(), _p(pad_sentlens), _p(b12_pad)), "phonlp_deep_biaffine_arc")
     return out, raw
 
 
 @torch.library.custom_op("phonlp_amd::deep_biaffine_label", mutates_args=())
 def deep_biaffine_label(hidden: Tensor, W12: Tensor, b12: Tensor, Wbt: Tensor, H: int, O: int,
-                        want_scores: bool) -> Tuple[Tensor, Tensor]:
+                        want_scores: bool, pad_sentlens: Optional[Tensor] = None,
+                        b12_pad: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
     """hidden [B,L,D] -> (label arg-max int32 [B,L,L], scores [B,L,O,L] or an empty tensor)."""
     _need(hidden, torch.float32, "hidden")
     B, L, D = hidden.shape
@@ -151,8 +153,8 @@ def deep_biaffine_label(hidden: Tensor, W12: Tensor, b12: Tensor, Wbt: Tensor, H
     nb = lib().phonlp_biaffine_label_ws_bytes(B, L, H, O)
     ws = _ws(nb, dev)
     check(lib().phonlp_deep_biaffine_label(_p(hidden), D, B, L, H, O, _p(W12), _p(b12), _p(Wbt), _p(out),
-                                           _p(scores) if want_scores else None, _p(ws), nb, _stream()),
-          "phonlp_deep_biaffine_label")
+                                           _p(scores) if want_scores else None, _p(ws), nb, _stream(),
+                                           _p(pad_sentlens), _p(b12_pad)), "phonlp_deep_biaffine_label")
     return out, scores
 
 
@@ -209,16 +211,18 @@ def mst_one_root(arc: Tensor, sentlens: Tensor) -> Tuple[Tensor, Tensor]:
 
 
 @torch.library.custom_op("phonlp_amd::label_project", mutates_args=())
-def label_project(hidden: Tensor, W12: Tensor, b12: Tensor, Wbt: Tensor, H: int, O: int) -> Tuple[Tensor, Tensor]:
-    """hidden [B,L,D] -> (XF [B*L, 2*KP], T [B*L, O*KP]): the label scorer's two GEMMs (include/phonlp_heads.h)."""
+def label_project(hidden: Tensor, W12: Tensor, b12: Tensor, Wbt: Tensor, H: int, O: int,
+                  pad_sentlens: Optional[Tensor] = None, b12_pad: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    """hidden [B,L,D] -> (XF [B*L, 2*KP], T [B*L, O*KP]): the label scorer's two GEMMs (include/phonlp_heads.h).
+    pad_sentlens / b12_pad select the folded form (rows before dep_hid, folded weights)."""
     _need(hidden, torch.float32, "hidden")
     B, L, D = hidden.shape
     dev = hidden.device
     KP = kp(H)
     XF = torch.empty((B * L, 2 * KP), dtype=torch.float32, device=dev)
     T = torch.empty((B * L, O * KP), dtype=torch.float32, device=dev)
-    check(lib().phonlp_label_project(_p(hidden), D, B, L, H, O, _p(W12), _p(b12), _p(Wbt), _p(XF), _p(T), _stream()),
-          "phonlp_label_project")
+    check(lib().phonlp_label_project(_p(hidden), D, B, L, H, O, _p(W12), _p(b12), _p(Wbt), _p(XF), _p(T), _stream(),
+                                     _p(pad_sentlens), _p(b12_pad)), "phonlp_label_project")
     return XF, T
 
 

@@ -496,3 +496,31 @@ def test_ner_entity_counts(dev, golden):
     ps = [[vocab[t] for t in pred[b, :lens[b]].tolist()] for b in range(B)]
     gs = [[vocab[t] for t in gold[b, :lens[b]].tolist()] for b in range(B)]
     assert got == list(O.ner_entity_counts(ps, gs))
+
+
+def test_folded_dep_hid_matches_unfolded(dev, engine):
+    """dep_hid folded into the scorers' first layer (annotate_batch's form) against the layer-by-layer form
+    (parser()): arc log-probs to 2e-4, identical non-finite pattern, and the padded rows of the projected features
+    bit-equal (they are relu(original bias) in both forms, whatever the padded input rows hold)."""
+    from phonlp_amd import HeadWeights, ops
+    from phonlp_amd import synthetic as S
+    B, L = 12, 70
+    w = HeadWeights.from_state_dict(S.make_state_dict(seed=11), dev)
+    lens = torch.tensor(S.make_sentlens(B, L, ragged=True, seed=4), dtype=torch.int32, device=dev)
+    feat = torch.randn(B, L, w.dep_hid_w.shape[1], generator=torch.Generator().manual_seed(2)).to(dev)
+    hidden = ops.dep_hidden(feat, lens, w.dep_hid_w, w.dep_hid_b)
+    garbage = feat.clone()
+    for b in range(B):
+        garbage[b, int(lens[b]):] = 1e3  # padded input rows must not matter in the folded form
+    arc_u, _ = ops.deep_biaffine_arc(hidden, w.arc_W12, w.arc_b12, w.arc_Wbt, w.H, w.n_arc_scorers, True, True, False)
+    arc_f, _ = ops.deep_biaffine_arc(garbage, w.arc_W12f, w.arc_b12f, w.arc_Wbt, w.H, w.n_arc_scorers, True, True, False,
+                                     lens, w.arc_b12)
+    _close(arc_f, arc_u, rtol=2e-4, atol=2e-4)
+    XFu, Tu = ops.label_project(hidden, w.lab_W12, w.lab_b12, w.lab_Wbt, w.H, w.O)
+    XFf, Tf = ops.label_project(garbage, w.lab_W12f, w.lab_b12f, w.lab_Wbt, w.H, w.O, lens, w.lab_b12)
+    XFu, XFf = XFu.view(B, L, -1).cpu(), XFf.view(B, L, -1).cpu()
+    for b in range(B):
+        n = int(lens[b])
+        assert torch.equal(XFu[b, n:], XFf[b, n:])
+        torch.testing.assert_close(XFf[b, :n], XFu[b, :n], rtol=2e-4, atol=2e-5)
+    torch.testing.assert_close(Tf.cpu(), Tu.cpu(), rtol=1e-3, atol=1e-4)
