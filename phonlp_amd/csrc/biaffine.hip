@@ -7,6 +7,8 @@
 //   T[b], X2[b]       --stage B (per sentence)--> scores[i][j][o], consumed in the epilogue:
 //       arc:   3 scorers combined, diagonal masked, row log-softmax staged through LDS
 //       label: running arg-max over o kept in registers; the B x L x L x O tensor never exists.
+#include <stdlib.h>
+
 #include "mma_f32.h"
 
 namespace phonlp {
@@ -40,6 +42,47 @@ __device__ __forceinline__ float wave_sum(float v) {
 // logsigmoid / softplus exactly as torch defines them (F.logsigmoid; F.softplus beta=1, threshold=20).
 __device__ __forceinline__ float log_sigmoid(float x) { return fminf(x, 0.f) - log1pf(expf(-fabsf(x))); }
 __device__ __forceinline__ float softplus(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+
+// arc[b,i,col] from the three scorers' raw outputs (ref annotate_model.py:192-211), diagonal masked.
+__device__ __forceinline__ float arc_combine(const ArcArgs &a, int b, int i, int col, float u, float lin, float dst,
+                                             long plane) {
+    const int L = a.L;
+    float v = u;
+    const int off = col - i;
+    if (a.S > 1) {
+        if (a.raw) {
+            const long e = ((long)b * L + i) * L + col;
+            a.raw[e] = u;
+            a.raw[plane + e] = lin;
+            a.raw[2 * plane + e] = dst;
+        }
+        if (a.use_lin) {
+            const float sg = off > 0 ? 1.f : (off < 0 ? -1.f : 0.f);
+            v += log_sigmoid(lin * sg);
+        }
+        if (a.use_dist) {
+            const float pred = 1.f + softplus(dst);
+            const float d = fabsf((float)off) - pred;
+            v += -logf(d * d / 2.f + 1.f);
+        }
+    } else if (a.raw) {
+        a.raw[((long)b * L + i) * L + col] = u;
+    }
+    if (off == 0) v = -INFINITY;
+    return v;
+}
+
+// row-wise log-softmax over all L head columns (padding columns included, ref :214), one wave per row
+__device__ __forceinline__ void arc_softmax_row(const float *x, float *o, int L, int lane) {
+    float m = -INFINITY;
+    for (int j = lane; j < L; j += 64) m = fmaxf(m, x[j]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int j = lane; j < L; j += 64) s += expf(x[j] - m);
+    s = wave_sum(s);
+    const float ls = logf(s);
+    for (int j = lane; j < L; j += 64) o[j] = (x[j] - m) - ls;
+}
 
 // One block = 32 dependents (rows i) of one sentence against all L heads.  4 waves; per 128-wide
 // column group wave w owns columns [32w, 32w+32).
@@ -99,49 +142,131 @@ __global__ __launch_bounds__(256) void arc_kernel(ArcArgs a) {
         for (int r = 0; r < 16; ++r) {
             const int row = acc_row(r, lane);
             const int i = i0 + row;
-            if (row < iv && col < L) {
-                const float u = acc0[0][0][r];
-                float v = u;
-                const int off = col - i;
-                if (a.S > 1) {
-                    const float lin = acc1[0][0][r], dst = acc2[0][0][r];
-                    if (a.raw) {
-                        const long e = ((long)b * L + i) * L + col;
-                        a.raw[e] = u;
-                        a.raw[plane + e] = lin;
-                        a.raw[2 * plane + e] = dst;
-                    }
-                    if (a.use_lin) {
-                        const float sg = off > 0 ? 1.f : (off < 0 ? -1.f : 0.f);
-                        v += log_sigmoid(lin * sg);
-                    }
-                    if (a.use_dist) {
-                        const float pred = 1.f + softplus(dst);
-                        const float d = fabsf((float)off) - pred;
-                        v += -logf(d * d / 2.f + 1.f);
-                    }
-                } else if (a.raw) {
-                    a.raw[((long)b * L + i) * L + col] = u;
-                }
-                if (off == 0) v = -INFINITY;
-                rowbuf[row * LP + col] = v;
-            }
+            if (row < iv && col < L)
+                rowbuf[row * LP + col] = arc_combine(a, b, i, col, acc0[0][0][r], acc1[0][0][r], acc2[0][0][r], plane);
         }
     }
     __syncthreads();
     // row-wise log-softmax over all L head columns (padding columns included, ref :214)
     for (int row = wave; row < iv && row < 32; row += 4) {
-        const float *x = rowbuf + row * LP;
-        float m = -INFINITY;
-        for (int j = lane; j < L; j += 64) m = fmaxf(m, x[j]);
-        m = wave_max(m);
-        float s = 0.f;
-        for (int j = lane; j < L; j += 64) s += expf(x[j] - m);
-        s = wave_sum(s);
-        const float ls = logf(s);
-        float *o = a.out + ((long)b * L + i0 + row) * L;
-        for (int j = lane; j < L; j += 64) o[j] = (x[j] - m) - ls;
+        arc_softmax_row(rowbuf + row * LP, a.out + ((long)b * L + i0 + row) * L, L, lane);
     }
+}
+
+// One scorer's contribution to arc[b,i,col], accumulated in the LDS row buffer in the reference's order
+// (unlabeled, + linearization term, + distance term; ref annotate_model.py:192-211).  Same arithmetic as arc_combine.
+__device__ __forceinline__ void arc_fold(const ArcArgs &a, int s, int b, int i, int col, float x, long plane, float *cell) {
+    const int L = a.L;
+    const int off = col - i;
+    if (a.raw) a.raw[s * plane + ((long)b * L + i) * L + col] = x;
+    float v;
+    if (s == 0) {
+        v = x;
+    } else if (s == 1) {
+        v = *cell;
+        if (a.use_lin) {
+            const float sg = off > 0 ? 1.f : (off < 0 ? -1.f : 0.f);
+            v += log_sigmoid(x * sg);
+        }
+    } else {
+        v = *cell;
+        if (a.use_dist) {
+            const float pred = 1.f + softplus(x);
+            const float d = fabsf((float)off) - pred;
+            v += -logf(d * d / 2.f + 1.f);
+        }
+    }
+    if (s == a.S - 1 && off == 0) v = -INFINITY;
+    *cell = v;
+}
+
+// The same for sentences of up to 192 words: one block = 128 dependents against all L heads, 4 waves as 2 x 2, each
+// wave 64 rows x 64 columns of a 128-wide column group.  The scorers run one after the other through ONE set of four
+// accumulator tiles; after a scorer's last slab its term is added to the LDS row buffer (each lane owns its cells, so
+// no barrier is needed between the terms).  A slab of X2 serves 128 dependents instead of 32: 4x less re-reading of
+// the head-side features and 8x more MFMA work per wave and barrier.
+template <int ENG>
+__global__ __launch_bounds__(256) void arc_kernel128(ArcArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *As = smem;
+    float *Bs = smem + 128 * PITCH;
+    float *rowbuf = smem + 256 * PITCH + 4 * 32 * 33;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    float *patch = smem + 256 * PITCH + wave * 32 * 33;
+    const int b = blockIdx.y, i0 = blockIdx.x * 128;
+    const int L = a.L, KP = a.KP, LP = a.LP;
+    const int iv = L - i0;
+    const int nk = (KP + BK - 1) / BK;
+    const int total = a.S * nk;
+    const float *Tb = a.T + ((long)b * L + i0) * a.ldT;
+    const long plane = (long)a.B * L * L;
+
+    for (int j0 = 0; j0 < L; j0 += 128) {
+        const int jv = L - j0;
+        const float *Xb = a.XF + ((long)b * L + j0) * a.ldx;
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        Slab<128, 256> ra, rb;
+        slab_load(ra, Tb, a.ldT, iv, 0, KP, tid);
+        slab_load(rb, Xb + KP, a.ldx, jv, 0, KP, tid);
+        __syncthreads();  // previous column group done with the staging buffers
+        slab_store(ra, As, tid);
+        slab_store(rb, Bs, tid);
+        __syncthreads();
+        int s = 0, kk = 0;
+        for (int it = 0; it < total; ++it) {
+            if (it + 1 < total) {
+                const int s2 = kk + 1 == nk ? s + 1 : s, k2 = (kk + 1 == nk ? 0 : kk + 1) * BK;
+                slab_load(ra, Tb + s2 * KP, a.ldT, iv, k2, KP, tid);
+                slab_load(rb, Xb + (2 * s2 + 1) * KP, a.ldx, jv, k2, KP, tid);
+            }
+            const float *Aw = As + wm * 64 * PITCH, *Bw = Bs + wn * 64 * PITCH;
+            mma_slab<2, 2, ENG>(Aw, Bw, lane, acc, slab_depth(kk * BK, KP));
+            __syncthreads();
+            if (it + 1 < total) {
+                slab_store(ra, As, tid);
+                slab_store(rb, Bs, tid);
+                __syncthreads();
+            }
+            if (++kk == nk) {
+                // accumulator tile -> this wave's LDS patch (static offsets), then a rolled loop over the patch: the
+                // unrolled form hoists 64 cell / raw addresses out of the slab loop and spills.
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            patch[acc_row(r, lane) * 33 + (lane & 31)] = acc[i][j][r];
+                            acc[i][j][r] = 0.f;
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        const int col = j0 + wn * 64 + j * 32 + (lane & 31);
+#pragma unroll 2
+                        for (int e = 0; e < 16; ++e) {
+                            const int pr = 2 * e + (lane >> 5);
+                            const int row = wm * 64 + i * 32 + pr;
+                            if (row < iv && col < L)
+                                arc_fold(a, s, b, i0 + row, col, patch[pr * 33 + (lane & 31)], plane, rowbuf + row * LP + col);
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                kk = 0;
+                ++s;
+            }
+        }
+    }
+    __syncthreads();
+    for (int row = wave; row < iv && row < 128; row += 4)
+        arc_softmax_row(rowbuf + row * LP, a.out + ((long)b * L + i0 + row) * L, L, lane);
 }
 
 // ---------------------------------------------------------------------------------------- label
@@ -376,11 +501,22 @@ extern "C" int phonlp_deep_biaffine_arc(const float *hidden, int D, int B, int L
         if (hipFuncSetAttribute((const void *)arc_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
                 hipSuccess ||
             hipFuncSetAttribute((const void *)arc_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+                hipSuccess ||
+            hipFuncSetAttribute((const void *)arc_kernel128<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+                hipSuccess ||
+            hipFuncSetAttribute((const void *)arc_kernel128<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
                 hipSuccess)
             return fail(PHONLP_ERR_LAUNCH, "deep_biaffine_arc: cannot raise the dynamic LDS limit");
         attr_set = true;
     }
     ProfScope ps("arc_stage_b", st);
+    static const bool rows32 = getenv("PHONLP_ARC_ROWS32") != nullptr;  // A/B switch
+    if (L <= 192 && !rows32) {
+        const size_t lds128 = (size_t)(256 * PITCH + 4 * 32 * 33 + 128 * a.LP) * sizeof(float);
+        if (gemm_engine()) hipLaunchKernelGGL(arc_kernel128<1>, dim3(ceil_div(L, 128), B), dim3(256), lds128, st, a);
+        else hipLaunchKernelGGL(arc_kernel128<0>, dim3(ceil_div(L, 128), B), dim3(256), lds128, st, a);
+        return check_launch("arc_kernel128");
+    }
     if (gemm_engine()) hipLaunchKernelGGL(arc_kernel<1>, dim3(ceil_div(L, 32), B), dim3(256), lds, st, a);
     else hipLaunchKernelGGL(arc_kernel<0>, dim3(ceil_div(L, 32), B), dim3(256), lds, st, a);
     return check_launch("arc_kernel");
