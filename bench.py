@@ -138,17 +138,20 @@ def main():
         torch.cuda.synchronize()
 
     engine = ops.get_gemm_engine()
-    other_ms = None
-    if world == 1:  # the other matrix engine on the same step, reported beside the headline number
-        ops.set_gemm_engine(1 - engine)
-        for _ in range(2):
-            step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(max(args.steps // 2, 1)):
-            step()
-        torch.cuda.synchronize()
-        other_ms = (time.perf_counter() - t0) / max(args.steps // 2, 1) * 1e3
+    other_ms = {}
+    if world == 1:  # the other matrix engines on the same step, reported beside the headline number
+        for other in (0, 1, 2):
+            if other == engine:
+                continue
+            ops.set_gemm_engine(other)
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(max(args.steps // 2, 1)):
+                step()
+            torch.cuda.synchronize()
+            other_ms[other] = (time.perf_counter() - t0) / max(args.steps // 2, 1) * 1e3
         ops.set_gemm_engine(engine)
     for _ in range(args.warmup):
         step()
@@ -178,11 +181,20 @@ def main():
         assert c[0] == sent and c[6] == 0, f"eval counts inconsistent: {c}"
         n, mean_ms, min_ms = kt.stats["linear:label_stage_a"]
         achieved = fl["label_stage_a"] * B / (mean_ms * 1e-3) / 1e12
-        # engine 1 spends six bf16 MFMA flops per fp32-equivalent flop: its ceiling in algorithmic flops is 2500/6
-        peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if engine == 1 else PEAK_F32_MFMA_TFLOPS
+        # engines 1 / 2 spend six bf16 / three f16 MFMA flops per fp32-equivalent flop: their ceilings in algorithmic
+        # flops are 2500/6 and 2500/3 (the same fraction as issued 16-bit MFMA flops over the 2500 dense peak)
+        peak = {0: PEAK_F32_MFMA_TFLOPS, 1: PEAK_BF16_MFMA_TFLOPS / 6.0, 2: PEAK_BF16_MFMA_TFLOPS / 3.0}[engine]
         eng_name = {0: "f32 MFMA (v_mfma_f32_32x32x2_f32)",
                     1: "bf16x6: fp32 operands split exactly into 3 bf16 pieces, 6 v_mfma_f32_32x32x16_bf16 products, "
-                       "f32 accumulate (fp32-grade error, tests/test_gpu_parity.py::test_engines_against_fp64)"}
+                       "f32 accumulate (fp32-grade error, tests/test_gpu_parity.py::test_engines_against_fp64)",
+                    2: "f16x3: fp32 operands scaled per row by a power of two and split into 2 f16 pieces once per "
+                       "element (split images), 3 v_mfma_f32_32x32x16_f16 products, f32 accumulate (fp32-grade error, "
+                       "tests/test_gpu_parity.py::test_engines_against_fp64); small layers and stage B run bf16x6"}
+        short = {0: "f32 MFMA", 1: "bf16x6", 2: "f16x3"}
+        kern = {0: "linear_kernel<128,128,2,2,1,0>", 1: "linear_split256_kernel<1>", 2: "linear_f16x3_kernel<1>"}
+        peak_note = {0: "dense fp32 MFMA peak",
+                     1: "algorithmic (fp32-equivalent) TFLOP/s; engine 1 peak = 2500 bf16 dense / 6 products",
+                     2: "algorithmic (fp32-equivalent) TFLOP/s; engine 2 peak = 2500 f16 dense / 3 products"}
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
@@ -193,17 +205,15 @@ def main():
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "gemm_engine": eng_name[engine],
-            "other_engine_ms_per_step": {eng_name[1 - engine].split(":")[0].split(" (")[0]: other_ms} if other_ms else None,
+            "other_engine_ms_per_step": {short[k]: v for k, v in other_ms.items()} if other_ms else None,
             "config": {"workload": "BASELINE config 3: synthetic B=256 L=128 full heads incl. Chu-Liu-Edmonds MST "
                                    "(E=768, H=400, n_rel=33, n_ner=9, n_upos=24), encoder outputs resident in HBM",
                        "batch_per_gpu": B, "seq_len": L, "parallelism": f"sentence-sharded x{world}"},
             "mfma_util_pct_whole_path": 100.0 * fl["total"] * B * args.steps / elapsed / (peak * 1e12),
-            "roofline": {"kernel": ("linear_split_kernel<1>" if engine == 1 else "linear_kernel<128,128,2,2,1,0>") +
-                                   " as bilinear stage A of the label scorer",
+            "roofline": {"kernel": kern[engine] + " as bilinear stage A of the label scorer",
                          "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic,
-                         "peak_note": "algorithmic (fp32-equivalent) TFLOP/s; engine 1 peak = 2500 bf16 dense / 6 products"
-                                      if engine == 1 else "dense fp32 MFMA peak",
+                         "peak_note": peak_note[engine],
                          "launches_timed": n, "mean_ms": mean_ms, "min_ms": min_ms,
                          "note": "timed inside the step, where the MST and tagger kernels share the chip with it "
                                  "on side streams",

@@ -58,12 +58,30 @@ const char *phonlp_last_error(void);
  *   0  v_mfma_f32_32x32x2_f32: exact fp32 multiply-add chain;
  *   1  "bf16x6": each fp32 operand split exactly into three bf16 pieces in registers, six
  *      v_mfma_f32_32x32x16_bf16 products, fp32 accumulate -- fp32-equivalent (dropped terms <= 3*2^-24 |a||b|),
- *      about twice as fast.  Same memory layouts, same entry points. */
+ *      about twice as fast.  Same memory layouts, same entry points.
+ *   2  "f16x3": as 1 for every entry point that takes fp32 operands; in addition the split-image entry points below
+ *      (phonlp_split_rows / phonlp_linear_split) are the engine proper: operands scaled per row by a power of two
+ *      and split exactly-to-2^-23 into two f16 pieces ONCE (weights at load, activations in one HBM-bound pass),
+ *      three v_mfma_f32_32x32x16_f16 products, fp32 accumulate -- the same fp32-grade error with half the MFMA
+ *      work of engine 1.  phonlp_amd/heads.py routes the large layers of annotate_batch through it. */
 int phonlp_set_gemm_engine(int engine);
 int phonlp_get_gemm_engine(void);
 
 int phonlp_linear(const float *X, int ldx, const float *W, int ldw, const float *bias, float *Y, int ldy,
                   int M, int N, int K, int relu, const int32_t *sentlens, int L, void *stream);
+
+/* Engine 2 dense layer on split images (same nn.Linear call sites as phonlp_linear: biaffine.py:27-29 stage A,
+ * biaffine.py:83-85 W1/W2).  Split image of a [rows, K] fp32 matrix = `planes` (phonlp_split_bytes(rows, K) bytes:
+ * row pitch 4*K16, K16 = K rounded up to 16; per 8 consecutive k: h[8] f16 then l[8] f16 of the row scaled by a
+ * power of two) + inv_scale [rows] fp32 (the inverse of that power of two).  K % 4 == 0, ldx % 4 == 0.
+ *   Y[M,N] = act((X . W^T) + bias)   with X, W given as split images; sentlens / L / pad_bias as in
+ * phonlp_linear and the folded form described under phonlp_deep_biaffine_arc (pad_bias may be NULL).
+ * `kind` only names the launch for the profiler: 0 generic, 1 label stage A, 2 label W1/W2, 3 arc W1/W2. */
+size_t phonlp_split_bytes(int rows, int K);
+int phonlp_split_rows(const float *X, int ldx, int rows, int K, void *planes, float *inv_scale, void *stream);
+int phonlp_linear_split(const void *Xp, const float *x_inv, const void *Wp, const float *w_inv, const float *bias,
+                        float *Y, int ldy, int M, int N, int K, int relu, const int32_t *sentlens, int L,
+                        const float *pad_bias, int kind, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Weight packing (one-time, at load).  Device-to-device kernels.
@@ -124,6 +142,15 @@ int phonlp_deep_biaffine_arc(const float *hidden, int D, int B, int L, int H, in
                              const float *W12, const float *b12, const float *Wbt,
                              float *arc_logp, float *raw_opt, void *ws, size_t ws_bytes, void *stream,
                              const int32_t *pad_sentlens, const float *b12_pad);
+
+/* The same from the scorers' first-layer features XF [B*L, n_scorers*2*KP] (what the W1/W2 layer of
+ * phonlp_deep_biaffine_arc writes: per scorer (relu(W1 x + b1) | 1 | 0.., relu(W2 x + b2) | 1 | 0..)), for callers
+ * that compute that layer themselves (engine 2: phonlp_linear_split on split images).  biaffine.py:62-65,21-37 +
+ * annotate_model.py:192-214. */
+size_t phonlp_biaffine_arc_scores_ws_bytes(int B, int L, int H, int n_scorers);
+int phonlp_biaffine_arc_scores(const float *XF, int B, int L, int H, int n_scorers, int use_lin, int use_dist,
+                               const float *Wbt, float *arc_logp, float *raw_opt, void *ws, size_t ws_bytes,
+                               void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Label scores -- annotate_model.py:190,215 (deprel DeepBiaffineScorer + .max(3)[1]):

@@ -16,6 +16,9 @@ SIGNATURES = {
     "phonlp_set_gemm_engine": (_i, [_i]),
     "phonlp_get_gemm_engine": (_i, []),
     "phonlp_linear": (_i, [_p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p, _i, _p]),
+    "phonlp_split_bytes": (_z, [_i, _i]),
+    "phonlp_split_rows": (_i, [_p, _i, _i, _i, _p, _p, _p]),
+    "phonlp_linear_split": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p]),
     "phonlp_pack_scorer_linear": (_i, [_p, _p, _p, _p, _i, _i, _p, _p, _p]),
     "phonlp_pack_bilinear": (_i, [_p, _i, _i, _p, _p]),
     "phonlp_pos_head_ws_bytes": (_z, [_i, _i, _i, _i, _i, _i]),
@@ -24,6 +27,8 @@ SIGNATURES = {
     "phonlp_dep_hidden": (_i, [_p, _i, _p, _i, _i, _p, _p, _p, _p]),
     "phonlp_biaffine_arc_ws_bytes": (_z, [_i, _i, _i, _i]),
     "phonlp_deep_biaffine_arc": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _z, _p, _p, _p]),
+    "phonlp_biaffine_arc_scores_ws_bytes": (_z, [_i, _i, _i, _i]),
+    "phonlp_biaffine_arc_scores": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _z, _p]),
     "phonlp_biaffine_label_ws_bytes": (_z, [_i, _i, _i, _i]),
     "phonlp_deep_biaffine_label": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _z, _p, _p, _p]),
     "phonlp_crf_viterbi": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _p]),

@@ -462,32 +462,11 @@ using namespace phonlp;
 
 extern "C" int phonlp_kp(int H) { return kp_of(H); }
 
-extern "C" size_t phonlp_biaffine_arc_ws_bytes(int B, int L, int H, int n_scorers) {
-    const size_t M = (size_t)B * L, KP = kp_of(H);
-    return align_up(M * n_scorers * 2 * KP * sizeof(float), 256) + align_up(M * n_scorers * KP * sizeof(float), 256);
-}
-
-extern "C" int phonlp_deep_biaffine_arc(const float *hidden, int D, int B, int L, int H, int n_scorers, int use_lin,
-                                        int use_dist, const float *W12, const float *b12, const float *Wbt,
-                                        float *arc_logp, float *raw_opt, void *ws, size_t ws_bytes, void *stream,
-                                        const int32_t *pad_sentlens, const float *b12_pad) {
-    if (!hidden || !W12 || !b12 || !Wbt || !arc_logp || B <= 0 || L <= 0 || H <= 0 || D <= 0)
-        return fail(PHONLP_ERR_SHAPE, "deep_biaffine_arc: bad argument");
-    if (n_scorers != 1 && n_scorers != 3) return fail(PHONLP_ERR_SHAPE, "deep_biaffine_arc: n_scorers must be 1 or 3");
-    if (n_scorers == 1 && (use_lin || use_dist))
-        return fail(PHONLP_ERR_SHAPE, "deep_biaffine_arc: use_lin/use_dist need n_scorers == 3");
-    if (L > 1024) return fail(PHONLP_ERR_UNSUPPORTED, "deep_biaffine_arc: L > 1024 does not fit the LDS row buffer");
-    if (ws_bytes < phonlp_biaffine_arc_ws_bytes(B, L, H, n_scorers) || !ws)
-        return fail(PHONLP_ERR_WORKSPACE, "deep_biaffine_arc: workspace too small");
-    hipStream_t st = as_stream(stream);
-    const int M = B * L, KP = kp_of(H), S = n_scorers;
-    float *XF = (float *)ws;
-    float *T = (float *)((char *)ws + align_up((size_t)M * S * 2 * KP * sizeof(float), 256));
-    if ((pad_sentlens == nullptr) != (b12_pad == nullptr))
-        return fail(PHONLP_ERR_SHAPE, "deep_biaffine_arc: pad_sentlens and b12_pad go together");
-    int rc = launch_linear("linear:arc_w12", hidden, D, W12, D, b12, XF, (long)S * 2 * KP, M, S * 2 * KP, D, 1, pad_sentlens,
-                           pad_sentlens ? L : 0, st, b12_pad);
-    if (rc) return rc;
+// stage A of the 1 or 3 arc scorers + the arc kernel, from the scorers' features XF [M, S*2*KP]
+static int arc_from_features(const float *XF, float *T, int B, int L, int KP, int S, int use_lin, int use_dist,
+                             const float *Wbt, float *arc_logp, float *raw_opt, hipStream_t st) {
+    const int M = B * L;
+    int rc;
     for (int s = 0; s < S; ++s) {
         rc = launch_linear("linear:arc_stage_a", XF + 2 * s * KP, (long)S * 2 * KP, Wbt + (long)s * KP * KP, KP, nullptr, T + s * KP,
                            (long)S * KP, M, KP, KP, 0, nullptr, 0, st);
@@ -520,6 +499,56 @@ extern "C" int phonlp_deep_biaffine_arc(const float *hidden, int D, int B, int L
     if (gemm_engine()) hipLaunchKernelGGL(arc_kernel<1>, dim3(ceil_div(L, 32), B), dim3(256), lds, st, a);
     else hipLaunchKernelGGL(arc_kernel<0>, dim3(ceil_div(L, 32), B), dim3(256), lds, st, a);
     return check_launch("arc_kernel");
+}
+
+extern "C" size_t phonlp_biaffine_arc_ws_bytes(int B, int L, int H, int n_scorers) {
+    const size_t M = (size_t)B * L, KP = kp_of(H);
+    return align_up(M * n_scorers * 2 * KP * sizeof(float), 256) + align_up(M * n_scorers * KP * sizeof(float), 256);
+}
+
+extern "C" int phonlp_deep_biaffine_arc(const float *hidden, int D, int B, int L, int H, int n_scorers, int use_lin,
+                                        int use_dist, const float *W12, const float *b12, const float *Wbt,
+                                        float *arc_logp, float *raw_opt, void *ws, size_t ws_bytes, void *stream,
+                                        const int32_t *pad_sentlens, const float *b12_pad) {
+    if (!hidden || !W12 || !b12 || !Wbt || !arc_logp || B <= 0 || L <= 0 || H <= 0 || D <= 0)
+        return fail(PHONLP_ERR_SHAPE, "deep_biaffine_arc: bad argument");
+    if (n_scorers != 1 && n_scorers != 3) return fail(PHONLP_ERR_SHAPE, "deep_biaffine_arc: n_scorers must be 1 or 3");
+    if (n_scorers == 1 && (use_lin || use_dist))
+        return fail(PHONLP_ERR_SHAPE, "deep_biaffine_arc: use_lin/use_dist need n_scorers == 3");
+    if (L > 1024) return fail(PHONLP_ERR_UNSUPPORTED, "deep_biaffine_arc: L > 1024 does not fit the LDS row buffer");
+    if (ws_bytes < phonlp_biaffine_arc_ws_bytes(B, L, H, n_scorers) || !ws)
+        return fail(PHONLP_ERR_WORKSPACE, "deep_biaffine_arc: workspace too small");
+    hipStream_t st = as_stream(stream);
+    const int M = B * L, KP = kp_of(H), S = n_scorers;
+    float *XF = (float *)ws;
+    float *T = (float *)((char *)ws + align_up((size_t)M * S * 2 * KP * sizeof(float), 256));
+    if ((pad_sentlens == nullptr) != (b12_pad == nullptr))
+        return fail(PHONLP_ERR_SHAPE, "deep_biaffine_arc: pad_sentlens and b12_pad go together");
+    int rc = launch_linear("linear:arc_w12", hidden, D, W12, D, b12, XF, (long)S * 2 * KP, M, S * 2 * KP, D, 1, pad_sentlens,
+                           pad_sentlens ? L : 0, st, b12_pad);
+    if (rc) return rc;
+    if (rc) return rc;
+    return arc_from_features(XF, T, B, L, KP, S, use_lin, use_dist, Wbt, arc_logp, raw_opt, st);
+}
+
+/* Arc scores from the scorers' first-layer features (engine 2 computes those with phonlp_linear_split). */
+extern "C" size_t phonlp_biaffine_arc_scores_ws_bytes(int B, int L, int H, int n_scorers) {
+    return align_up((size_t)B * L * n_scorers * kp_of(H) * sizeof(float), 256);
+}
+
+extern "C" int phonlp_biaffine_arc_scores(const float *XF, int B, int L, int H, int n_scorers, int use_lin, int use_dist,
+                                          const float *Wbt, float *arc_logp, float *raw_opt, void *ws, size_t ws_bytes,
+                                          void *stream) {
+    if (!XF || !Wbt || !arc_logp || B <= 0 || L <= 0 || H <= 0) return fail(PHONLP_ERR_SHAPE, "biaffine_arc_scores: bad argument");
+    if (n_scorers != 1 && n_scorers != 3) return fail(PHONLP_ERR_SHAPE, "biaffine_arc_scores: n_scorers must be 1 or 3");
+    if (n_scorers == 1 && (use_lin || use_dist))
+        return fail(PHONLP_ERR_SHAPE, "biaffine_arc_scores: use_lin/use_dist need n_scorers == 3");
+    if (L > 1024) return fail(PHONLP_ERR_UNSUPPORTED, "biaffine_arc_scores: L > 1024 does not fit the LDS row buffer");
+    if (((uintptr_t)XF & 15)) return fail(PHONLP_ERR_SHAPE, "biaffine_arc_scores: XF must be 16-byte aligned");
+    if (ws_bytes < phonlp_biaffine_arc_scores_ws_bytes(B, L, H, n_scorers) || !ws)
+        return fail(PHONLP_ERR_WORKSPACE, "biaffine_arc_scores: workspace too small");
+    return arc_from_features(XF, (float *)ws, B, L, kp_of(H), n_scorers, use_lin, use_dist, Wbt, arc_logp, raw_opt,
+                             as_stream(stream));
 }
 
 extern "C" size_t phonlp_biaffine_label_ws_bytes(int B, int L, int H, int O) {

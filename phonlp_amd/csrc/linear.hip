@@ -5,95 +5,9 @@
 
 #include <type_traits>
 
-#include "mma_f32.h"
+#include "linear_args.h"
 
 namespace phonlp {
-
-struct LinearArgs {
-    const float *X;
-    const float *W;
-    const float *bias;
-    const float *pad_bias;  // NULL: padded rows are written as zeros; else as act(pad_bias) (see launch_linear)
-    float *Y;
-    const int32_t *sentlens;
-    long ldx, ldw, ldy;
-    int M, N, K, L;
-    int relu;
-    int num_m, num_n;
-};
-
-// Epilogue shared by the dense-layer kernels: the wave's accumulators are transposed through a per-wave LDS
-// patch (32 rows x (TN*32 + 4) floats at lds + wave * 32 * EP; the caller guarantees WM*WN such patches fit and
-// that no wave still reads the slab images they alias) so that every global store is a 16-byte-per-lane row
-// segment; bias / ReLU / padding mask fused.
-template <int TM, int TN, int WM, int WN>
-__device__ __forceinline__ void linear_epilogue(f32x16 (&acc)[TM][TN], float *lds, const LinearArgs &a, int m0, int n0,
-                                                int wm, int wn, int lane, int wave) {
-            constexpr int WCOLS = TN * 32, EP = WCOLS + 4;
-            float *ep = lds + wave * 32 * EP;
-            constexpr int LPR = WCOLS / 4;   // lanes per row
-            constexpr int RPI = 64 / LPR;    // rows per wave-instruction
-            const int c4 = (lane % LPR) * 4;
-            const int col = n0 + wn * WCOLS + c4;
-            const int rsub = lane / LPR;
-            const bool vec_ok = ((a.ldy & 3) == 0) && (((uintptr_t)a.Y & 15) == 0) && (col + 3 < a.N);
-            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (a.bias) {
-                if (col < a.N) bv.x = a.bias[col];
-                if (col + 1 < a.N) bv.y = a.bias[col + 1];
-                if (col + 2 < a.N) bv.z = a.bias[col + 2];
-                if (col + 3 < a.N) bv.w = a.bias[col + 3];
-            }
-            float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);  // value of a padded row
-            if (a.pad_bias) {
-                if (col < a.N) pv.x = a.pad_bias[col];
-                if (col + 1 < a.N) pv.y = a.pad_bias[col + 1];
-                if (col + 2 < a.N) pv.z = a.pad_bias[col + 2];
-                if (col + 3 < a.N) pv.w = a.pad_bias[col + 3];
-                if (a.relu) { pv.x = fmaxf(pv.x, 0.f); pv.y = fmaxf(pv.y, 0.f); pv.z = fmaxf(pv.z, 0.f); pv.w = fmaxf(pv.w, 0.f); }
-            }
-            unsigned live[TM];
-    #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                live[i] = 0xFFFFFFFFu;
-                if (a.sentlens) {
-                    live[i] = 0;
-    #pragma unroll
-                    for (int it = 0; it < 32 / RPI; ++it) {
-                        const int row = m0 + (wm * TM + i) * 32 + it * RPI + rsub;
-                        if (row < a.M && (row % a.L) < a.sentlens[row / a.L]) live[i] |= 1u << it;
-                    }
-                }
-            }
-    #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-    #pragma unroll
-                for (int j = 0; j < TN; ++j)
-    #pragma unroll
-                    for (int r = 0; r < 16; ++r) ep[acc_row(r, lane) * EP + j * 32 + (lane & 31)] = acc[i][j][r];
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    #pragma unroll
-                for (int it = 0; it < 32 / RPI; ++it) {
-                    const int lrow = it * RPI + rsub;
-                    const int row = m0 + (wm * TM + i) * 32 + lrow;
-                    float4 v = *reinterpret_cast<const float4 *>(ep + lrow * EP + c4);
-                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-                    if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                    if (!((live[i] >> it) & 1u)) v = pv;
-                    if (row >= a.M || col >= a.N) continue;
-                    float *y = a.Y + (long)row * a.ldy + col;
-                    if (vec_ok) {
-                        *reinterpret_cast<float4 *>(y) = v;
-                    } else {
-                        y[0] = v.x;
-                        if (col + 1 < a.N) y[1] = v.y;
-                        if (col + 2 < a.N) y[2] = v.z;
-                        if (col + 3 < a.N) y[3] = v.w;
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            }
-}
 
 // BM x BN block tile, WM x WN waves, each wave a (BM/WM) x (BN/WN) sub-tile.  TAG only names the
 // instantiation (TAG 1 = bilinear stage A of the label scorer, so profilers list it on its own row).
@@ -821,16 +735,18 @@ __global__ __launch_bounds__(256, 2) void linear_split256_kernel(LinearArgs a) {
     linear_epilogue<TM, TN, WM, WN>(acc, reinterpret_cast<float *>(lds), a, m0, n0, wm, wn, lane, wave);
 }
 
-// GEMM engine shared by every MFMA kernel of the library: 0 = f32 MFMA (exact fp32 chain), 1 = bf16x6 (default).
+// GEMM engine shared by every MFMA kernel of the library: 0 = f32 MFMA (exact fp32 chain), 1 = bf16x6, 2 = f16x3 on
+// the split-image entry points (linear_f16x3.hip) and bf16x6 everywhere else (default).
 static int g_engine = -1;
 int gemm_engine() {
     if (g_engine < 0) {
         const char *e = getenv("PHONLP_GEMM_ENGINE");
-        g_engine = e ? (atoi(e) != 0) : 1;
+        const int v = e ? atoi(e) : 2;
+        g_engine = v < 0 ? 0 : (v > 2 ? 2 : v);
     }
     return g_engine;
 }
-void set_gemm_engine(int e) { g_engine = e != 0; }
+void set_gemm_engine(int e) { g_engine = e; }
 
 // Grid size.  One block per tile by default.  PHONLP_GEMM_PERSISTENT=1 selects a persistent grid of two blocks
 // per CU walking strided tiles (+3 % when the GEMM has the chip to itself, but its static partition stalls
@@ -937,7 +853,7 @@ __global__ void pack_bilinear_kernel(const float *weight, int H, int O, int KP, 
 using namespace phonlp;
 
 extern "C" int phonlp_set_gemm_engine(int engine) {
-    if (engine != 0 && engine != 1) return fail(PHONLP_ERR_SHAPE, "set_gemm_engine: 0 (f32 MFMA) or 1 (bf16x6)");
+    if (engine < 0 || engine > 2) return fail(PHONLP_ERR_SHAPE, "set_gemm_engine: 0 (f32 MFMA), 1 (bf16x6) or 2 (f16x3)");
     set_gemm_engine(engine);
     return PHONLP_OK;
 }

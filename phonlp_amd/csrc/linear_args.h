@@ -1,0 +1,106 @@
+// Arguments and the shared epilogue of the dense-layer kernels (linear.hip, linear_f16x3.hip).
+#pragma once
+#include "mma_f32.h"
+
+namespace phonlp {
+
+struct LinearArgs {
+    const float *X;
+    const float *W;
+    const float *bias;
+    const float *pad_bias;  // NULL: padded rows are written as zeros; else as act(pad_bias) (see launch_linear)
+    float *Y;
+    const int32_t *sentlens;
+    long ldx, ldw, ldy;
+    int M, N, K, L;
+    int relu;
+    int num_m, num_n;
+    // engine 2 only (linear_f16x3.hip): per-row / per-column powers of two that undo the operand scaling
+    const float *row_scale, *col_scale;
+};
+
+// Epilogue shared by the dense-layer kernels: the wave's accumulators are transposed through a per-wave LDS
+// patch (32 rows x (TN*32 + 4) floats at lds + wave * 32 * EP; the caller guarantees WM*WN such patches fit and
+// that no wave still reads the slab images they alias) so that every global store is a 16-byte-per-lane row
+// segment; bias / ReLU / padding mask fused.
+template <int TM, int TN, int WM, int WN>
+__device__ __forceinline__ void linear_epilogue(f32x16 (&acc)[TM][TN], float *lds, const LinearArgs &a, int m0, int n0,
+                                                int wm, int wn, int lane, int wave) {
+            constexpr int WCOLS = TN * 32, EP = WCOLS + 4;
+            float *ep = lds + wave * 32 * EP;
+            constexpr int LPR = WCOLS / 4;   // lanes per row
+            constexpr int RPI = 64 / LPR;    // rows per wave-instruction
+            const int c4 = (lane % LPR) * 4;
+            const int col = n0 + wn * WCOLS + c4;
+            const int rsub = lane / LPR;
+            const bool vec_ok = ((a.ldy & 3) == 0) && (((uintptr_t)a.Y & 15) == 0) && (col + 3 < a.N);
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.bias) {
+                if (col < a.N) bv.x = a.bias[col];
+                if (col + 1 < a.N) bv.y = a.bias[col + 1];
+                if (col + 2 < a.N) bv.z = a.bias[col + 2];
+                if (col + 3 < a.N) bv.w = a.bias[col + 3];
+            }
+            float4 cs = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (a.col_scale) {
+                if (col < a.N) cs.x = a.col_scale[col];
+                if (col + 1 < a.N) cs.y = a.col_scale[col + 1];
+                if (col + 2 < a.N) cs.z = a.col_scale[col + 2];
+                if (col + 3 < a.N) cs.w = a.col_scale[col + 3];
+            }
+            float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);  // value of a padded row
+            if (a.pad_bias) {
+                if (col < a.N) pv.x = a.pad_bias[col];
+                if (col + 1 < a.N) pv.y = a.pad_bias[col + 1];
+                if (col + 2 < a.N) pv.z = a.pad_bias[col + 2];
+                if (col + 3 < a.N) pv.w = a.pad_bias[col + 3];
+                if (a.relu) { pv.x = fmaxf(pv.x, 0.f); pv.y = fmaxf(pv.y, 0.f); pv.z = fmaxf(pv.z, 0.f); pv.w = fmaxf(pv.w, 0.f); }
+            }
+            unsigned live[TM];
+    #pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                live[i] = 0xFFFFFFFFu;
+                if (a.sentlens) {
+                    live[i] = 0;
+    #pragma unroll
+                    for (int it = 0; it < 32 / RPI; ++it) {
+                        const int row = m0 + (wm * TM + i) * 32 + it * RPI + rsub;
+                        if (row < a.M && (row % a.L) < a.sentlens[row / a.L]) live[i] |= 1u << it;
+                    }
+                }
+            }
+    #pragma unroll
+            for (int i = 0; i < TM; ++i) {
+    #pragma unroll
+                for (int j = 0; j < TN; ++j)
+    #pragma unroll
+                    for (int r = 0; r < 16; ++r) ep[acc_row(r, lane) * EP + j * 32 + (lane & 31)] = acc[i][j][r];
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    #pragma unroll
+                for (int it = 0; it < 32 / RPI; ++it) {
+                    const int lrow = it * RPI + rsub;
+                    const int row = m0 + (wm * TM + i) * 32 + lrow;
+                    float4 v = *reinterpret_cast<const float4 *>(ep + lrow * EP + c4);
+                    if (a.row_scale) {  // (v * 2^-ka) * 2^-kb: exact
+                        const float rs = a.row_scale[row < a.M ? row : a.M - 1];
+                        v.x = v.x * rs * cs.x; v.y = v.y * rs * cs.y; v.z = v.z * rs * cs.z; v.w = v.w * rs * cs.w;
+                    }
+                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                    if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    if (!((live[i] >> it) & 1u)) v = pv;
+                    if (row >= a.M || col >= a.N) continue;
+                    float *y = a.Y + (long)row * a.ldy + col;
+                    if (vec_ok) {
+                        *reinterpret_cast<float4 *>(y) = v;
+                    } else {
+                        y[0] = v.x;
+                        if (col + 1 < a.N) y[1] = v.y;
+                        if (col + 2 < a.N) y[2] = v.z;
+                        if (col + 3 < a.N) y[3] = v.w;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
+}
+
+}  // namespace phonlp

@@ -1,0 +1,251 @@
+// Engine 2, "f16x3": fp32-equivalent dense layers on the f16 matrix pipe with HALF the MFMA work of engine 1.
+//
+// An fp32 operand row x is scaled by a power of two s (exact) so that its largest magnitude lies in
+// [2^14, 2^15), and split into two f16 pieces  h = rn16(s x),  l = rn16(s x - h)  (the subtraction is exact).
+// h + l carries 22-23 significand bits plus the sign trick of round-to-nearest: |s x - h - l| <= 2^-23 |s x| for
+// every element within 2^16 of the row maximum; smaller elements lose relative precision against f16's
+// subnormal grid (2^-24), i.e. at most 2^-39 of the row maximum in absolute terms -- far below one fp32 rounding
+// of the row's large elements.  The product is  a.b ~ al.bh + ah.bl + ah.bh  (the dropped al.bl <= 2^-22 |a||b|
+// worst case, 2^-24 typical), three v_mfma_f32_32x32x16_f16 accumulated in fp32 smallest terms first, and the
+// epilogue multiplies by the two inverse scales (exact).  Measured against an fp64 product the error is that of
+// engine 1 (tests/test_gpu_parity.py::test_engines_against_fp64).
+//
+// The split is done ONCE PER ELEMENT by split_rows_kernel (weights: at load; activations: one HBM-bound pass,
+// 8 bytes per element), not once per tile as engine 1 does while staging, so the GEMM's loop is nothing but
+// global_load_dwordx4 -> ds_write_b128 -> ds_read_b128 -> MFMA.
+//
+// Split image of a [rows, K] matrix: row pitch K16*4 bytes (K16 = K rounded up to 16, zero filled); every group of
+// 8 consecutive k is 32 bytes: h[8] then l[8].  A k16 stage of a row is therefore one 64-byte segment of four
+// 16-byte chunks (h0-7, l0-7, h8-15, l8-15), and an MFMA fragment (lane r, half hh: k = 8hh..8hh+7 of row r) is
+// chunk 2hh (h) / 2hh+1 (l).  inv_scale[row] = 1/s.
+#include <stdlib.h>
+#include <string.h>
+
+#include "linear_args.h"
+
+namespace phonlp {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+#define PHONLP_F16_MFMA(A, B, C) \
+    __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B), C, 0, 0, 0)
+
+// ------------------------------------------------------------------------------------------ split
+// One wavefront per row.  K % 4 == 0, X 16-byte aligned, ldx % 4 == 0.
+__global__ __launch_bounds__(256) void split_rows_kernel(const float *X, long ldx, int rows, int K, int K16,
+                                                          unsigned char *planes, float *inv_scale) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float *x = X + (long)row * ldx;
+    unsigned mx = 0;
+    for (int c = lane * 4; c < K; c += 256) {
+        const float4 v = *reinterpret_cast<const float4 *>(x + c);
+        mx = max(mx, __float_as_uint(v.x) & 0x7FFFFFFFu);
+        mx = max(mx, __float_as_uint(v.y) & 0x7FFFFFFFu);
+        mx = max(mx, __float_as_uint(v.z) & 0x7FFFFFFFu);
+        mx = max(mx, __float_as_uint(v.w) & 0x7FFFFFFFu);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
+    int E = (int)(mx >> 23);  // biased exponent of the row maximum
+    E = E < 16 ? 16 : (E > 254 ? 254 : E);
+    const float scale = __uint_as_float((unsigned)(268 - E) << 23);  // 2^(14 - (E - 127)): maximum -> [2^14, 2^15)
+    if (lane == 0) inv_scale[row] = __uint_as_float((unsigned)(E - 14) << 23);
+    unsigned char *out = planes + (long)row * K16 * 4;
+    for (int g = lane; g * 8 < K16; g += 64) {
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int c = g * 8 + q * 4;
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < K) t = *reinterpret_cast<const float4 *>(x + c);
+            v[q * 4 + 0] = t.x; v[q * 4 + 1] = t.y; v[q * 4 + 2] = t.z; v[q * 4 + 3] = t.w;
+        }
+        f16x8 h, l;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float s = v[e] * scale;            // exact (power of two, no overflow: |s| < 2^15)
+            h[e] = (_Float16)s;                      // round to nearest even
+            l[e] = (_Float16)(s - (float)h[e]);      // the difference is exact in fp32
+        }
+        *reinterpret_cast<f16x8 *>(out + g * 32) = h;
+        *reinterpret_cast<f16x8 *>(out + g * 32 + 16) = l;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ GEMM
+// 256 x 128 block tile, four waves of 128 x 64 (8 accumulator tiles), k16 stages, two 24 KB LDS buffers, one
+// barrier per stage; two blocks per CU cover each other's barriers.  a.X / a.W are the split images (row pitch
+// a.ldx / a.ldw BYTES), a.K = K16.  Per stage and wave: 12 ds_read_b128 feed 24 MFMAs; per thread 6 global
+// loads + 6 ds_write_b128 and no other VALU work.
+//
+// LDS image of a stage: row R at R*64 bytes (rows 0-255 A tile, 256-383 B tile), chunk c stored at slot
+// c ^ ((R>>2)&3): the 16 rows of a ds_read_b128 lane group cover all 64 banks, and so do the 4 rows x 4 chunks of
+// a ds_write_b128 lane group.  Rows past M / N are not zero-filled: their pointers are clamped to the last valid
+// row and the garbage only reaches outputs the epilogue never stores.
+template <int TAG>
+__global__ __launch_bounds__(256, 2) void linear_f16x3_kernel(LinearArgs a) {
+    constexpr int BM = 256, BN = 128, WM = 2, WN = 2, TM = 4, TN = 2;
+    constexpr int ROWS = BM + BN, BUF = ROWS * 64;
+    static_assert(WM * WN * 32 * (TN * 32 + 4) * 4 <= 2 * BUF, "epilogue patch must fit");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int ntiles = a.num_m * a.num_n;
+    const int nst = a.K >> 4;
+    int m0, n0;
+    {   // one tile per block; blocks b, b+8, ... (one XCD) take a contiguous chunk of a 4-tall column-major walk
+        const int xg = blockIdx.x & 7, jl = blockIdx.x >> 3;
+        const int q = ntiles >> 3, r = ntiles & 7;
+        const int t = (xg < r ? xg * (q + 1) : r * (q + 1) + (xg - r) * q) + jl;
+        constexpr int GM = 4;
+        const int per_group = GM * a.num_n;
+        const int g = t / per_group;
+        const int first_m = g * GM;
+        const int gsz = (a.num_m - first_m) < GM ? (a.num_m - first_m) : GM;
+        const int in = t - g * per_group;
+        m0 = (first_m + in % gsz) * BM;
+        n0 = (in / gsz) * BN;
+    }
+    // staging map: thread -> chunk c = tid&3 of rows (tid>>2) + 64q; q 0-3 are A rows, 4-5 B rows
+    const int r0 = tid >> 2, c = tid & 3;
+    const unsigned char *src[6];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int row = m0 + r0 + 64 * q;
+        row = row < a.M ? row : a.M - 1;
+        src[q] = reinterpret_cast<const unsigned char *>(a.X) + (long)row * a.ldx + c * 16;
+    }
+#pragma unroll
+    for (int q = 4; q < 6; ++q) {
+        int row = n0 + r0 + 64 * (q - 4);
+        row = row < a.N ? row : a.N - 1;
+        src[q] = reinterpret_cast<const unsigned char *>(a.W) + (long)row * a.ldw + c * 16;
+    }
+    const int wofs = r0 * 64 + ((c ^ ((r0 >> 2) & 3)) << 4);
+    u32x4 R[6];
+    auto load_stage = [&](int st) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) R[q] = *reinterpret_cast<const u32x4 *>(src[q] + (long)st * 64);
+    };
+    auto store_stage = [&](unsigned char *buf) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) *reinterpret_cast<u32x4 *>(buf + wofs + q * 64 * 64) = R[q];
+    };
+
+    const int r = lane & 31, hh = lane >> 5;
+    const int sw = (r >> 2) & 3;
+    const int off_h = ((2 * hh) ^ sw) << 4, off_l = ((2 * hh + 1) ^ sw) << 4;
+    const int a_ofs = (wm * 128 + r) * 64;
+    const int b_ofs = (BM + wn * 64 + r) * 64;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    struct Frags {
+        u32x4 ah[TM], al[TM], bh[TN], bl[TN];
+    };
+    auto read_frags = [&](const unsigned char *buf, Frags &f) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            f.bh[j] = *reinterpret_cast<const u32x4 *>(buf + b_ofs + j * 2048 + off_h);
+            f.bl[j] = *reinterpret_cast<const u32x4 *>(buf + b_ofs + j * 2048 + off_l);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            f.al[i] = *reinterpret_cast<const u32x4 *>(buf + a_ofs + i * 2048 + off_l);
+            f.ah[i] = *reinterpret_cast<const u32x4 *>(buf + a_ofs + i * 2048 + off_h);
+        }
+    };
+    auto mma_frags = [&](const Frags &f) {
+#define PHONLP_X3_ROUND(AA, BB)                      \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)   \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] = PHONLP_F16_MFMA(f.AA[i], f.BB[j], acc[i][j]);
+        PHONLP_X3_ROUND(al, bh)
+        PHONLP_X3_ROUND(ah, bl)
+        PHONLP_X3_ROUND(ah, bh)
+#undef PHONLP_X3_ROUND
+    };
+
+    // prologue: stage 0 in buffer 0, stage 1 in registers
+    load_stage(0);
+    store_stage(lds);
+    if (nst > 1) load_stage(1);
+    lds_barrier();
+    for (int s = 0; s < nst; ++s) {
+        unsigned char *cur = lds + (s & 1) * BUF, *nxt = lds + ((s + 1) & 1) * BUF;
+        Frags f;
+        read_frags(cur, f);
+        if (s + 1 < nst) store_stage(nxt);
+        if (s + 2 < nst) load_stage(s + 2);
+        mma_frags(f);
+        lds_barrier();
+    }
+    linear_epilogue<TM, TN, WM, WN>(acc, reinterpret_cast<float *>(lds), a, m0, n0, wm, wn, lane, wave);
+}
+
+int launch_linear_f16x3(const char *tag, const void *Xp, long pitch_x, const float *x_inv, const void *Wp, long pitch_w,
+                        const float *w_inv, const float *bias, float *Y, long ldy, int M, int N, int K16, int relu,
+                        const int32_t *sentlens, int L, hipStream_t stream, const float *pad_bias) {
+    if (!Xp || !Wp || !x_inv || !w_inv || !Y || M <= 0 || N <= 0 || K16 <= 0)
+        return fail(PHONLP_ERR_SHAPE, "linear_split: bad argument");
+    if ((K16 & 15) || (pitch_x & 15) || (pitch_w & 15) || pitch_x < 4L * K16 || pitch_w < 4L * K16 ||
+        ((uintptr_t)Xp & 15) || ((uintptr_t)Wp & 15))
+        return fail(PHONLP_ERR_SHAPE, "linear_split: split images must be 16-byte aligned with K16 %% 16 == 0");
+    if (sentlens && L <= 0) return fail(PHONLP_ERR_SHAPE, "linear_split: sentlens given but L <= 0");
+    if (pad_bias && !sentlens) return fail(PHONLP_ERR_SHAPE, "linear_split: pad_bias needs sentlens");
+    LinearArgs a{reinterpret_cast<const float *>(Xp), reinterpret_cast<const float *>(Wp), bias, pad_bias, Y, sentlens,
+                 pitch_x, pitch_w, ldy, M, N, K16, L, relu, ceil_div(M, 256), ceil_div(N, 128), x_inv, w_inv};
+    constexpr int LDS = 2 * 384 * 64;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)linear_f16x3_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess ||
+            hipFuncSetAttribute((const void *)linear_f16x3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+            return fail(PHONLP_ERR_LAUNCH, "linear_split: cannot raise the dynamic LDS limit");
+        attr_set = true;
+    }
+    const bool stage_a = tag && !strcmp(tag, "linear:label_stage_a");
+    ProfScope ps(tag, stream);
+    const dim3 g(a.num_m * a.num_n);
+    if (stage_a) hipLaunchKernelGGL((linear_f16x3_kernel<1>), g, dim3(256), LDS, stream, a);
+    else hipLaunchKernelGGL((linear_f16x3_kernel<0>), g, dim3(256), LDS, stream, a);
+    return check_launch("linear_f16x3_kernel");
+}
+
+}  // namespace phonlp
+
+using namespace phonlp;
+
+extern "C" size_t phonlp_split_bytes(int rows, int K) {
+    if (rows <= 0 || K <= 0) return 0;
+    return (size_t)rows * (size_t)((K + 15) / 16 * 16) * 4;
+}
+
+extern "C" int phonlp_split_rows(const float *X, int ldx, int rows, int K, void *planes, float *inv_scale, void *stream) {
+    if (!X || !planes || !inv_scale || rows <= 0 || K <= 0) return fail(PHONLP_ERR_SHAPE, "split_rows: bad argument");
+    if ((K & 3) || (ldx & 3) || ((uintptr_t)X & 15) || ((uintptr_t)planes & 15))
+        return fail(PHONLP_ERR_SHAPE, "split_rows: K, ldx must be multiples of 4 and X, planes 16-byte aligned");
+    const int K16 = (K + 15) / 16 * 16;
+    ProfScope ps("split_rows", as_stream(stream));
+    hipLaunchKernelGGL(split_rows_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, as_stream(stream), X, (long)ldx, rows, K,
+                       K16, reinterpret_cast<unsigned char *>(planes), inv_scale);
+    return check_launch("split_rows_kernel");
+}
+
+extern "C" int phonlp_linear_split(const void *Xp, const float *x_inv, const void *Wp, const float *w_inv,
+                                   const float *bias, float *Y, int ldy, int M, int N, int K, int relu,
+                                   const int32_t *sentlens, int L, const float *pad_bias, int kind, void *stream) {
+    if (K <= 0) return fail(PHONLP_ERR_SHAPE, "linear_split: bad argument");
+    const int K16 = (K + 15) / 16 * 16;
+    static const char *tags[] = {"linear_split", "linear:label_stage_a", "linear:label_w12", "linear:arc_w12"};
+    if (kind < 0 || kind > 3) return fail(PHONLP_ERR_SHAPE, "linear_split: kind must be 0..3");
+    return launch_linear_f16x3(tags[kind], Xp, 4L * K16, x_inv, Wp, 4L * K16, w_inv, bias, Y, ldy, M, N, K16, relu, sentlens,
+                               L, as_stream(stream), pad_bias);
+}

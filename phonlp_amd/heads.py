@@ -51,6 +51,10 @@ class HeadWeights:
     n_arc_scorers: int
     linearization: bool
     distance: bool
+    # engine 2 split images (planes, inv_scale) of the weights annotate_batch's large layers read
+    arc_W12f_s: Optional[tuple] = None
+    lab_W12f_s: Optional[tuple] = None
+    lab_Wbt_s: Optional[tuple] = None
 
     @classmethod
     def from_state_dict(cls, sd: Dict[str, torch.Tensor], device="cuda", linearization=True, distance=True):
@@ -111,6 +115,8 @@ class HeadWeights:
             lab_W12=lab[0], lab_b12=lab[1], lab_Wbt=lab[2],
             arc_W12f=arcf[0], arc_b12f=arcf[1], lab_W12f=labf[0], lab_b12f=labf[1],
             H=H, O=O, n_arc_scorers=n_arc, linearization=bool(linearization), distance=bool(distance),
+            arc_W12f_s=tuple(ops.split_rows(arcf[0])), lab_W12f_s=tuple(ops.split_rows(labf[0])),
+            lab_Wbt_s=tuple(ops.split_rows(lab[2])),
         )
 
 
@@ -211,8 +217,16 @@ class TaskHeads:
         feat, _, _ = ops.pos_head(enc_dep.contiguous(), lens_d, w.upos_hid_w, w.upos_hid_b, w.upos_clf_w,
                                   w.upos_clf_b, w.emb_dep)
         # dep_hid is folded into the scorers' first layers (HeadWeights.from_state_dict): the scorers read `feat`
-        arc_logp, _ = ops.deep_biaffine_arc(feat, w.arc_W12f, w.arc_b12f, w.arc_Wbt, w.H, w.n_arc_scorers,
-                                            w.linearization, w.distance, False, lens_d, w.arc_b12)
+        split = ops.get_gemm_engine() == 2 and w.lab_Wbt_s is not None
+        B, Ld, D = feat.shape
+        if split:  # engine 2: the large layers run on split images (one split pass per activation matrix)
+            featp, feati = ops.split_rows(feat.view(B * Ld, D))
+            XFa = ops.linear_split(featp, feati, w.arc_W12f_s[0], w.arc_W12f_s[1], w.arc_b12f, D, True, lens_d, Ld,
+                                   w.arc_b12, 3)
+            arc_logp = ops.biaffine_arc_scores(XFa, B, Ld, w.arc_Wbt, w.H, w.n_arc_scorers, w.linearization, w.distance)
+        else:
+            arc_logp, _ = ops.deep_biaffine_arc(feat, w.arc_W12f, w.arc_b12f, w.arc_Wbt, w.H, w.n_arc_scorers,
+                                                w.linearization, w.distance, False, lens_d, w.arc_b12)
         arc_done = torch.cuda.Event()
         arc_done.record(main)
         # MST beside the label scorer
@@ -222,7 +236,13 @@ class TaskHeads:
             heads, status = ops.mst_one_root(arc_logp, lens_d)
             mst_done = torch.cuda.Event()
             mst_done.record(s_mst)
-        XF, T = ops.label_project(feat, w.lab_W12f, w.lab_b12f, w.lab_Wbt, w.H, w.O, lens_d, w.lab_b12)
+        if split:
+            XF = ops.linear_split(featp, feati, w.lab_W12f_s[0], w.lab_W12f_s[1], w.lab_b12f, D, True, lens_d, Ld,
+                                  w.lab_b12, 2)
+            x1p, x1i = ops.split_rows(XF[:, :ops.kp(w.H)])
+            T = ops.linear_split(x1p, x1i, w.lab_Wbt_s[0], w.lab_Wbt_s[1], None, ops.kp(w.H), False, None, 0, None, 1)
+        else:
+            XF, T = ops.label_project(feat, w.lab_W12f, w.lab_b12f, w.lab_Wbt, w.H, w.O, lens_d, w.lab_b12)
         if join:
             fin = main
         else:

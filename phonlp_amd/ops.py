@@ -301,3 +301,48 @@ def ner_entity_counts(pred: Tensor, gold: Tensor, sentlens: Tensor, tag_kind: Te
 @ner_entity_counts.register_fake
 def _(pred, gold, sentlens, tag_kind, tag_type):
     return torch.empty(3, dtype=torch.int64, device=pred.device)
+
+
+@torch.library.custom_op("phonlp_amd::split_rows", mutates_args=())
+def split_rows(x: Tensor) -> Tuple[Tensor, Tensor]:
+    """x [rows, K] fp32 (row stride free, unit column stride) -> engine-2 split image (planes uint8 [rows, 4*K16],
+    inv_scale fp32 [rows]); include/phonlp_heads.h phonlp_split_rows."""
+    if not x.is_cuda or x.dtype != torch.float32 or x.dim() != 2 or x.stride(1) != 1:
+        raise ValueError("split_rows: expected a 2-d fp32 ROCm tensor with unit column stride")
+    rows, K = x.shape
+    nb = lib().phonlp_split_bytes(rows, K)
+    planes = torch.empty((rows, nb // rows), dtype=torch.uint8, device=x.device)
+    inv = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    check(lib().phonlp_split_rows(_p(x), x.stride(0), rows, K, _p(planes), _p(inv), _stream()), "phonlp_split_rows")
+    return planes, inv
+
+
+@torch.library.custom_op("phonlp_amd::linear_split", mutates_args=())
+def linear_split(xp: Tensor, x_inv: Tensor, wp: Tensor, w_inv: Tensor, bias: Optional[Tensor], K: int, relu: bool,
+                 sentlens: Optional[Tensor], L: int, pad_bias: Optional[Tensor], kind: int) -> Tensor:
+    """Engine-2 dense layer y = act(x @ w.T + bias) on split images (split_rows); K = the unsplit inner size."""
+    _need(xp, torch.uint8, "xp")
+    _need(wp, torch.uint8, "wp")
+    _need(x_inv, torch.float32, "x_inv")
+    _need(w_inv, torch.float32, "w_inv")
+    M, N = xp.shape[0], wp.shape[0]
+    if xp.shape[1] != wp.shape[1] or xp.shape[1] != lib().phonlp_split_bytes(1, K):
+        raise ValueError("linear_split: split images do not match K")
+    y = torch.empty((M, N), dtype=torch.float32, device=xp.device)
+    check(lib().phonlp_linear_split(_p(xp), _p(x_inv), _p(wp), _p(w_inv), _p(bias), _p(y), N, M, N, K, int(relu),
+                                    _p(sentlens), L, _p(pad_bias), kind, _stream()), "phonlp_linear_split")
+    return y
+
+
+@torch.library.custom_op("phonlp_amd::biaffine_arc_scores", mutates_args=())
+def biaffine_arc_scores(XF: Tensor, B: int, L: int, Wbt: Tensor, H: int, n_scorers: int, use_lin: bool,
+                        use_dist: bool) -> Tensor:
+    """XF [B*L, n_scorers*2*KP] (the arc scorers' first-layer features) -> arc log-probs [B,L,L]."""
+    _need(XF, torch.float32, "XF")
+    dev = XF.device
+    out = torch.empty((B, L, L), dtype=torch.float32, device=dev)
+    nb = lib().phonlp_biaffine_arc_scores_ws_bytes(B, L, H, n_scorers)
+    ws = _ws(nb, dev)
+    check(lib().phonlp_biaffine_arc_scores(_p(XF), B, L, H, n_scorers, int(use_lin), int(use_dist), _p(Wbt), _p(out),
+                                           None, _p(ws), nb, _stream()), "phonlp_biaffine_arc_scores")
+    return out

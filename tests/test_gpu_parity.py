@@ -23,7 +23,7 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.fixture(params=[0, 1], ids=["f32mfma", "bf16x6"])
+@pytest.fixture(params=[0, 1, 2], ids=["f32mfma", "bf16x6", "f16x3"])
 def engine(request, dev):
     """Runs a GEMM-bearing test once per matrix engine of the library (include/phonlp_heads.h)."""
     from phonlp_amd import ops
@@ -69,10 +69,72 @@ def test_linear_vs_torch_fp32(dev, engine, M, N, K, relu, masked):
     torch.testing.assert_close(got.cpu(), ref, rtol=1e-4, atol=1e-4)
 
 
+def _linear_split(ops, x, w, bias=None, relu=False, lens=None, L=0, pad_bias=None):
+    """Engine 2 proper: both operands as split images (include/phonlp_heads.h phonlp_split_rows / _linear_split)."""
+    xp, xi = ops.split_rows(x)
+    wp, wi = ops.split_rows(w)
+    return ops.linear_split(xp, xi, wp, wi, bias, x.shape[1], relu, lens, L, pad_bias, 0)
+
+
+@pytest.mark.parametrize("M,N,K,relu,masked", [
+    (300, 70, 868, True, False), (129, 9, 868, True, True), (64, 416, 416, False, False),
+    (1000, 868, 868, False, True), (257, 24, 400, False, True), (1500, 300, 868, True, True), (1027, 129, 20, False, False),
+    (2048, 128, 4, False, False), (128, 128, 32, True, False), (5, 3, 4, False, False), (700, 413, 408, True, True),
+])
+def test_linear_split_vs_torch_fp32(dev, M, N, K, relu, masked):
+    """The f16x3 dense layer on split images against torch fp32, same cases as the fp32-operand entry point; with
+    `masked` also the folded-form padding rows (relu(pad_bias))."""
+    from phonlp_amd import ops
+    g = torch.Generator().manual_seed(M * 7 + N)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    pb = torch.randn(N, generator=g)
+    L = 50
+    B = (M + L - 1) // L
+    lens = torch.randint(1, L + 1, (B,), generator=g).to(torch.int32)
+    ref = x @ w.t() + b
+    if relu:
+        ref = torch.relu(ref)
+    if masked:
+        rows = torch.arange(M)
+        live = ((rows % L) < lens[rows // L].long()).unsqueeze(1)
+        ref = torch.where(live, ref, (torch.relu(pb) if relu else pb).expand_as(ref))
+    got = _linear_split(ops, x.to(dev), w.to(dev), b.to(dev), relu, lens.to(dev) if masked else None, L if masked else 0,
+                        pb.to(dev) if masked else None)
+    torch.testing.assert_close(got.cpu(), ref, rtol=1e-4, atol=1e-4)
+
+
+def test_split_rows_image(dev):
+    """The split image itself: h + l reproduces the scaled row to 2^-23 relative for elements within 2^16 of the row
+    maximum, zero rows and zero padding stay zero, inv_scale is the exact inverse power of two, strided input."""
+    from phonlp_amd import ops
+    g = torch.Generator().manual_seed(5)
+    rows, K = 37, 100
+    x = torch.randn(rows, 2 * K, generator=g) * torch.exp(4 * torch.randn(rows, 1, generator=g))
+    x[3] = 0
+    x[5, :K] *= 1e-30
+    xs = x[:, :K]
+    planes, inv = ops.split_rows(x.to(dev)[:, :K])
+    K16 = (K + 15) // 16 * 16
+    img = planes.cpu().view(torch.float16).view(rows, K16 // 8, 2, 8).double()
+    h, l = img[:, :, 0, :].reshape(rows, K16), img[:, :, 1, :].reshape(rows, K16)
+    assert (h[:, K:] == 0).all() and (l[:, K:] == 0).all()
+    inv = inv.cpu().double()
+    assert torch.equal(torch.log2(inv), torch.log2(inv).round())
+    rec = (h + l)[:, :K] * inv.unsqueeze(1)
+    mx = xs.abs().max(1, keepdim=True).values.double().clamp_min(1e-300)
+    assert ((h.abs().max(1).values < 2.0 ** 15).all())
+    big = xs.abs().double() >= mx * 2.0 ** -15
+    assert ((rec - xs.double()).abs()[big] <= xs.abs().double()[big] * 2.0 ** -23).all()
+    assert ((rec - xs.double()).abs() <= torch.maximum(xs.abs().double() * 2.0 ** -23, mx * 2.0 ** -38)).all()
+    assert (rec[3] == 0).all()
+
+
 @pytest.mark.parametrize("M,N,K", [(512, 640, 401), (256, 868, 868), (384, 256, 4096), (1300, 650, 401), (1024, 256, 2048)])
 def test_engines_against_fp64(dev, M, N, K):
-    """Both matrix engines are fp32-grade: error against an fp64 product, in units of sum_k |a||b| (the scale an
-    fp32 dot product's rounding error lives on), stays below 1e-6, and the bf16-split engine is no worse than
+    """All matrix engines are fp32-grade: error against an fp64 product, in units of sum_k |a||b| (the scale an
+    fp32 dot product's rounding error lives on), stays below 1e-6, and the split engines are no worse than
     the f32 MFMA chain.  Rows carry widely different magnitudes (exp(2*N(0,1))) to exercise the split."""
     from phonlp_amd import ops
     g = torch.Generator().manual_seed(K)
@@ -88,10 +150,12 @@ def test_engines_against_fp64(dev, M, N, K):
             ops.set_gemm_engine(e)
             y = ops.linear(x.to(dev), w.to(dev), None, False, None, 0).cpu().double()
             errs.append(((y - ref).abs() / scale).max().item())
+        y = _linear_split(ops, x.to(dev), w.to(dev)).cpu().double()
+        errs.append(((y - ref).abs() / scale).max().item())
     finally:
         ops.set_gemm_engine(before)
-    assert errs[0] < 1e-6 and errs[1] < 1e-6, errs
-    assert errs[1] <= 1.5 * errs[0] + 1e-8, errs
+    assert max(errs) < 1e-6, errs
+    assert errs[1] <= 1.5 * errs[0] + 1e-8 and errs[2] <= 1.5 * errs[0] + 1e-8, errs
 
 
 # ------------------------------------------------------------------------------------------ Viterbi
