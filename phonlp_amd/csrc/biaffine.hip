@@ -456,6 +456,120 @@ __global__ __launch_bounds__(256) void label_at_heads_kernel(const float *T, con
     }
 }
 
+
+// The same on the "rows interleaved by 4" image T4 that engine 2's stage A writes (linear_f16x3.hip:
+// T4[(m/4)*N + c][m%4] = T[m][c], N = O*KP): one block per group of four consecutive rows m = 4g .. 4g+3.  The four
+// heads' h2 rows are staged in LDS interleaved the same way (xs4[d2] = the four words' h2[d2]), so one 16-byte load of
+// T4 and one ds_read_b128 feed four words.  Per word: lanes stride over d2 with an fmaf chain, a fixed-order
+// cross-lane sum, strict '>' in ascending o (the summation order differs from label_at_heads_kernel's, so the two
+// agree to fp32 rounding, not bit for bit).
+__global__ __launch_bounds__(256) void label_at_heads4_kernel(const float *T4, const float *XF, const int32_t *heads,
+                                                               const int32_t *sentlens, int M, int L, int O, int KP,
+                                                               int32_t *rels, float *best_opt) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];  // [KP] float4
+    __shared__ float wbest[4][4];
+    __shared__ int warg[4][4];
+    const int grp = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int hrow[4];  // row of XF that holds the head's features, -1 = word without a label
+    bool any = false;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const int m = grp * 4 + w;
+        hrow[w] = -1;
+        if (m < M) {
+            const int b = m / L, i = m - b * L;
+            if (i >= 1 && i < sentlens[b]) {
+                const int h = heads[m];
+                if (h >= 0 && h < L) hrow[w] = b * L + h;
+            }
+        }
+        any = any || hrow[w] >= 0;
+    }
+    if (!any) {  // block-uniform
+        if (tid < 4 && grp * 4 + tid < M) {
+            rels[grp * 4 + tid] = 0;
+            if (best_opt) best_opt[grp * 4 + tid] = 0.f;
+        }
+        return;
+    }
+    for (int c = tid; c < KP; c += 256) {
+        float4 v;
+        v.x = hrow[0] >= 0 ? XF[(long)hrow[0] * 2 * KP + KP + c] : 0.f;
+        v.y = hrow[1] >= 0 ? XF[(long)hrow[1] * 2 * KP + KP + c] : 0.f;
+        v.z = hrow[2] >= 0 ? XF[(long)hrow[2] * 2 * KP + KP + c] : 0.f;
+        v.w = hrow[3] >= 0 ? XF[(long)hrow[3] * 2 * KP + KP + c] : 0.f;
+        reinterpret_cast<float4 *>(xs)[c] = v;
+    }
+    __syncthreads();
+    const float4 *xs4 = reinterpret_cast<const float4 *>(xs);
+    const float4 *Tg = reinterpret_cast<const float4 *>(T4) + (long)grp * O * KP;
+    float bestv[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int besto[4] = {0, 0, 0, 0};
+    for (int o = wave; o < O; o += 12) {  // three relations per trip: their loads are in flight together
+        float s[3][4];
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) s[u][w] = 0.f;
+        for (int c = lane; c < KP; c += 64) {  // lanes stride over d2: every wave-load is 1 KiB contiguous
+            const float4 xv = xs4[c];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int ou = o + 4 * u;
+                if (ou < O) {
+                    const float4 tv = Tg[(long)ou * KP + c];
+                    s[u][0] = fmaf(tv.x, xv.x, s[u][0]);
+                    s[u][1] = fmaf(tv.y, xv.y, s[u][1]);
+                    s[u][2] = fmaf(tv.z, xv.z, s[u][2]);
+                    s[u][3] = fmaf(tv.w, xv.w, s[u][3]);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int ou = o + 4 * u;
+            // four sums over 64 lanes in 7 exchanges: halves trade word pairs, quarters trade words, then a
+            // 16-lane butterfly; lane l ends with the total of word (l>>4)&3 ... (fixed order: deterministic)
+            const bool hi32 = lane & 32, hi16 = lane & 16;
+            float a0 = hi32 ? s[u][2] : s[u][0], a1 = hi32 ? s[u][3] : s[u][1];      // kept pair
+            const float g0 = hi32 ? s[u][0] : s[u][2], g1 = hi32 ? s[u][1] : s[u][3];  // given away
+            a0 += __shfl_xor(g0, 32);
+            a1 += __shfl_xor(g1, 32);
+            float v = hi16 ? a1 : a0;
+            v += __shfl_xor(hi16 ? a0 : a1, 16);
+#pragma unroll
+            for (int sft = 8; sft > 0; sft >>= 1) v += __shfl_xor(v, sft);
+            // lanes 0-15: word 0, 16-31: word 1, 32-47: word 2, 48-63: word 3
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const float t = __shfl(v, 16 * w);
+                if (ou < O && t > bestv[w]) {
+                    bestv[w] = t;
+                    besto[w] = ou;
+                }
+            }
+        }
+    }
+    if (lane < 4) {
+        wbest[wave][lane] = bestv[lane];
+        warg[wave][lane] = besto[lane];
+    }
+    __syncthreads();
+    if (tid < 4 && grp * 4 + tid < M) {
+        float bv = wbest[0][tid];
+        int bo = warg[0][tid];
+        for (int w = 1; w < 4; ++w)
+            if (wbest[w][tid] > bv || (wbest[w][tid] == bv && warg[w][tid] < bo)) {
+                bv = wbest[w][tid];
+                bo = warg[w][tid];
+            }
+        const bool ok = hrow[tid] >= 0;
+        rels[grp * 4 + tid] = ok ? bo : 0;
+        if (best_opt) best_opt[grp * 4 + tid] = ok ? bv : 0.f;
+    }
+}
+
 }  // namespace phonlp
 
 using namespace phonlp;
@@ -609,6 +723,22 @@ extern "C" int phonlp_label_at_heads(const float *T, const float *XF, const int3
     hipLaunchKernelGGL(label_at_heads_kernel, dim3(B * L), dim3(256), (size_t)KP * sizeof(float), st, T, XF, heads,
                        sentlens, L, O, KP, rels, best_opt);
     return check_launch("label_at_heads_kernel");
+}
+
+extern "C" int phonlp_label_at_heads_rows4(const float *T4, const float *XF, const int32_t *heads,
+                                           const int32_t *sentlens, int B, int L, int H, int O, int32_t *rels,
+                                           float *best_opt, void *stream) {
+    if (!T4 || !XF || !heads || !sentlens || !rels || B <= 0 || L <= 0 || H <= 0 || O <= 0)
+        return fail(PHONLP_ERR_SHAPE, "label_at_heads_rows4: bad argument");
+    const int KP = kp_of(H);
+    if ((size_t)KP * sizeof(float4) > 60 * 1024) return fail(PHONLP_ERR_UNSUPPORTED, "label_at_heads_rows4: H too large for the LDS rows");
+    if (((uintptr_t)T4 & 15) || ((uintptr_t)XF & 15)) return fail(PHONLP_ERR_SHAPE, "label_at_heads_rows4: T4, XF must be 16-byte aligned");
+    hipStream_t st = as_stream(stream);
+    ProfScope ps("label_at_heads", st);
+    const int M = B * L;
+    hipLaunchKernelGGL(label_at_heads4_kernel, dim3((M + 3) / 4), dim3(256), (size_t)KP * sizeof(float4), st, T4, XF, heads,
+                       sentlens, M, L, O, KP, rels, best_opt);
+    return check_launch("label_at_heads4_kernel");
 }
 
 extern "C" int phonlp_gather_labels(const int32_t *label_argmax, const int32_t *heads, const int32_t *sentlens, int B,

@@ -17,6 +17,8 @@ struct LinearArgs {
     int num_m, num_n;
     // engine 2 only (linear_f16x3.hip): per-row / per-column powers of two that undo the operand scaling
     const float *row_scale, *col_scale;
+    int rows4;  // linear_f16x3.hip: write Y in the "rows interleaved by 4" layout straight from the accumulators
+    int dbg;  // timing-only ablations (PHONLP_X3_ABLATION): 1 = epilogue without its global stores, 2 = no epilogue
 };
 
 // Epilogue shared by the dense-layer kernels: the wave's accumulators are transposed through a per-wave LDS
@@ -89,6 +91,7 @@ __device__ __forceinline__ void linear_epilogue(f32x16 (&acc)[TM][TN], float *ld
                     if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                     if (!((live[i] >> it) & 1u)) v = pv;
                     if (row >= a.M || col >= a.N) continue;
+                    if (a.dbg == 1 && v.x != 1234.5f) continue;
                     float *y = a.Y + (long)row * a.ldy + col;
                     if (vec_ok) {
                         *reinterpret_cast<float4 *>(y) = v;

@@ -75,6 +75,48 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float *X, long ld
 }
 
 // ------------------------------------------------------------------------------------------ GEMM
+// Epilogue in the "rows interleaved by 4" layout: Y4[(m/4)*N + n][m%4] = C[m][n].  In the MFMA C/D layout four
+// consecutive accumulator registers of a lane are four consecutive ROWS of one column, so a lane's float4 is stored
+// as it stands (no LDS transpose): lanes 0-31 of a wave-store write 512 contiguous bytes, lanes 32-63 the next row
+// group's 512.  Only scaling (exact powers of two); no bias / activation / padding in this form.  Y4 holds
+// ceil(M/4) row groups, so a group that straddles M is stored whole.
+template <int TM, int TN>
+__device__ __forceinline__ void rows4_epilogue(f32x16 (&acc)[TM][TN], const LinearArgs &a, int m0, int n0, int wm, int wn,
+                                               int lane) {
+    float cs[TN];
+    int col[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        col[j] = n0 + (wn * TN + j) * 32 + (lane & 31);
+        cs[j] = (a.col_scale && col[j] < a.N) ? a.col_scale[col[j]] : 1.f;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int row = m0 + (wm * TM + i) * 32 + 8 * g + 4 * (lane >> 5);  // multiple of 4
+            if (row >= a.M) continue;
+            float4 rs = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (a.row_scale) {
+                rs.x = a.row_scale[row];
+                rs.y = a.row_scale[row + 1 < a.M ? row + 1 : a.M - 1];
+                rs.z = a.row_scale[row + 2 < a.M ? row + 2 : a.M - 1];
+                rs.w = a.row_scale[row + 3 < a.M ? row + 3 : a.M - 1];
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if (col[j] >= a.N) continue;
+                float4 v;
+                v.x = acc[i][j][4 * g + 0] * rs.x * cs[j];
+                v.y = acc[i][j][4 * g + 1] * rs.y * cs[j];
+                v.z = acc[i][j][4 * g + 2] * rs.z * cs[j];
+                v.w = acc[i][j][4 * g + 3] * rs.w * cs[j];
+                if (a.dbg == 1 && v.x != 1234.5f) continue;
+                *reinterpret_cast<float4 *>(a.Y + ((long)(row >> 2) * a.N + col[j]) * 4) = v;
+            }
+        }
+}
+
 // 256 x 128 block tile, four waves of 128 x 64 (8 accumulator tiles), k16 stages, two 24 KB LDS buffers, one
 // barrier per stage; two blocks per CU cover each other's barriers.  a.X / a.W are the split images (row pitch
 // a.ldx / a.ldw BYTES), a.K = K16.  Per stage and wave: 12 ds_read_b128 feed 24 MFMAs; per thread 6 global
@@ -188,12 +230,143 @@ __global__ __launch_bounds__(256, 2) void linear_f16x3_kernel(LinearArgs a) {
         mma_frags(f);
         lds_barrier();
     }
+    if (a.rows4) {
+        rows4_epilogue<TM, TN>(acc, a, m0, n0, wm, wn, lane);
+        return;
+    }
+    linear_epilogue<TM, TN, WM, WN>(acc, reinterpret_cast<float *>(lds), a, m0, n0, wm, wn, lane, wave);
+}
+
+// The same tile with the operands streamed global -> LDS by the LDS-DMA path (global_load_lds_dwordx4: 16 bytes per
+// lane land at M0 + lane*16, no VGPR staging) into a ring of THREE stage buffers, so the loads of stage s+2 are in
+// flight while stage s is multiplied: two whole stages (~1500-3000 cycles) cover the L2 / Infinity-Cache latency that
+// the register-staged loop above (one stage of lookahead) leaves exposed.  A wave-load covers 16 rows x 64 bytes; lane
+// i writes slot i&3 of row i>>2, so it FETCHES chunk (i&3) ^ ((i>>4)&3) of that row: the swizzle of the LDS image is
+// applied on the global side.  The DMA and its s_waitcnt are inline asm: hipcc's own waitcnt insertion would make
+// every LDS read wait for all LDS-DMA loads in flight (it cannot tell the ring buffers apart).
+__device__ __forceinline__ void lds_dma16(const unsigned char *gptr, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_addr), "v"(gptr) : "memory", "m0");
+}
+
+template <int TAG>
+__global__ __launch_bounds__(256, 2) void linear_f16x3_dma_kernel(LinearArgs a) {
+    constexpr int BM = 256, BN = 128, WM = 2, WN = 2, TM = 4, TN = 2, NBUF = 3;
+    constexpr int ROWS = BM + BN, BUF = ROWS * 64;
+    static_assert(WM * WN * 32 * (TN * 32 + 4) * 4 <= NBUF * BUF, "epilogue patch must fit");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int ntiles = a.num_m * a.num_n;
+    const int nst = a.K >> 4;
+    int m0, n0;
+    {
+        const int xg = blockIdx.x & 7, jl = blockIdx.x >> 3;
+        const int q = ntiles >> 3, r = ntiles & 7;
+        const int t = (xg < r ? xg * (q + 1) : r * (q + 1) + (xg - r) * q) + jl;
+        constexpr int GM = 4;
+        const int per_group = GM * a.num_n;
+        const int g = t / per_group;
+        const int first_m = g * GM;
+        const int gsz = (a.num_m - first_m) < GM ? (a.num_m - first_m) : GM;
+        const int in = t - g * per_group;
+        m0 = (first_m + in % gsz) * BM;
+        n0 = (in / gsz) * BN;
+    }
+    // wave-load u = 4q + wave (q = 0..5) fills rows 16u .. 16u+15 of the stage image (A rows 0-255, B rows 256-383)
+    const int lr = lane >> 2, chunk = (lane & 3) ^ ((lane >> 4) & 3);
+    const unsigned char *src[6];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int row = m0 + 16 * (4 * q + wave) + lr;
+        row = row < a.M ? row : a.M - 1;
+        src[q] = reinterpret_cast<const unsigned char *>(a.X) + (long)row * a.ldx + chunk * 16;
+    }
+#pragma unroll
+    for (int q = 4; q < 6; ++q) {
+        int row = n0 + 16 * (4 * (q - 4) + wave) + lr;
+        row = row < a.N ? row : a.N - 1;
+        src[q] = reinterpret_cast<const unsigned char *>(a.W) + (long)row * a.ldw + chunk * 16;
+    }
+    const unsigned lds0 = (unsigned)(uintptr_t)lds + (unsigned)__builtin_amdgcn_readfirstlane(wave) * 1024u;
+    auto issue_stage = [&](int st, int buf) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) lds_dma16(src[q] + (long)st * 64, lds0 + (unsigned)(buf * BUF + q * 4096));
+    };
+
+    const int r = lane & 31, hh = lane >> 5;
+    const int sw = (r >> 2) & 3;
+    const int off_h = ((2 * hh) ^ sw) << 4, off_l = ((2 * hh + 1) ^ sw) << 4;
+    const int a_ofs = (wm * 128 + r) * 64;
+    const int b_ofs = (BM + wn * 64 + r) * 64;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    issue_stage(0, 0);
+    if (nst > 1) {
+        issue_stage(1, 1);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    int cur = 0;
+    for (int s = 0; s < nst; ++s) {
+        const unsigned char *buf = lds + cur * BUF;
+        const int nxt2 = cur == 0 ? 2 : cur - 1;  // (cur + 2) % 3: last read in iteration s-1, behind that barrier
+        if (s + 2 < nst) issue_stage(s + 2, nxt2);
+        u32x4 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            bh[j] = *reinterpret_cast<const u32x4 *>(buf + b_ofs + j * 2048 + off_h);
+            bl[j] = *reinterpret_cast<const u32x4 *>(buf + b_ofs + j * 2048 + off_l);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            al[i] = *reinterpret_cast<const u32x4 *>(buf + a_ofs + i * 2048 + off_l);
+            ah[i] = *reinterpret_cast<const u32x4 *>(buf + a_ofs + i * 2048 + off_h);
+        }
+#define PHONLP_X3_ROUND(AA, BB)                      \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)   \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] = PHONLP_F16_MFMA(AA[i], BB[j], acc[i][j]);
+        PHONLP_X3_ROUND(al, bh)
+        PHONLP_X3_ROUND(ah, bl)
+        PHONLP_X3_ROUND(ah, bh)
+#undef PHONLP_X3_ROUND
+        // stage s+1 (issued one iteration ago) must have landed before anyone reads it; the 6 loads of stage s+2 issued
+        // above may stay in flight
+        if (s + 2 < nst) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();
+        cur = cur == 2 ? 0 : cur + 1;
+    }
+    if (a.dbg == 2) {  // timing only: keep the accumulators alive without the epilogue
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) t += acc[i][j][e];
+        if (t == 1234.5f) a.Y[tid] = t;
+        return;
+    }
+    if (a.rows4) {
+        rows4_epilogue<TM, TN>(acc, a, m0, n0, wm, wn, lane);
+        return;
+    }
     linear_epilogue<TM, TN, WM, WN>(acc, reinterpret_cast<float *>(lds), a, m0, n0, wm, wn, lane, wave);
 }
 
 int launch_linear_f16x3(const char *tag, const void *Xp, long pitch_x, const float *x_inv, const void *Wp, long pitch_w,
                         const float *w_inv, const float *bias, float *Y, long ldy, int M, int N, int K16, int relu,
-                        const int32_t *sentlens, int L, hipStream_t stream, const float *pad_bias) {
+                        const int32_t *sentlens, int L, hipStream_t stream, const float *pad_bias, int rows4 = 0) {
     if (!Xp || !Wp || !x_inv || !w_inv || !Y || M <= 0 || N <= 0 || K16 <= 0)
         return fail(PHONLP_ERR_SHAPE, "linear_split: bad argument");
     if ((K16 & 15) || (pitch_x & 15) || (pitch_w & 15) || pitch_x < 4L * K16 || pitch_w < 4L * K16 ||
@@ -203,20 +376,33 @@ int launch_linear_f16x3(const char *tag, const void *Xp, long pitch_x, const flo
     if (pad_bias && !sentlens) return fail(PHONLP_ERR_SHAPE, "linear_split: pad_bias needs sentlens");
     LinearArgs a{reinterpret_cast<const float *>(Xp), reinterpret_cast<const float *>(Wp), bias, pad_bias, Y, sentlens,
                  pitch_x, pitch_w, ldy, M, N, K16, L, relu, ceil_div(M, 256), ceil_div(N, 128), x_inv, w_inv};
-    constexpr int LDS = 2 * 384 * 64;
+    constexpr int LDS = 2 * 384 * 64, LDS_DMA = 3 * 384 * 64;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void *)linear_f16x3_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess ||
-            hipFuncSetAttribute((const void *)linear_f16x3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+            hipFuncSetAttribute((const void *)linear_f16x3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess ||
+            hipFuncSetAttribute((const void *)linear_f16x3_dma_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DMA) != hipSuccess ||
+            hipFuncSetAttribute((const void *)linear_f16x3_dma_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DMA) != hipSuccess)
             return fail(PHONLP_ERR_LAUNCH, "linear_split: cannot raise the dynamic LDS limit");
         attr_set = true;
     }
     const bool stage_a = tag && !strcmp(tag, "linear:label_stage_a");
+    static const bool reg_staged = getenv("PHONLP_X3_REG_STAGED") != nullptr;  // A/B switch: register-staged loop
+    static const int abl = getenv("PHONLP_X3_ABLATION") ? atoi(getenv("PHONLP_X3_ABLATION")) : 0;  // timing only
+    a.dbg = abl;
+    a.rows4 = rows4;
+    if (rows4 && (bias || sentlens || relu || ((uintptr_t)Y & 15)))
+        return fail(PHONLP_ERR_SHAPE, "linear_split: the rows-by-4 output takes no bias / activation / padding mask");
     ProfScope ps(tag, stream);
     const dim3 g(a.num_m * a.num_n);
-    if (stage_a) hipLaunchKernelGGL((linear_f16x3_kernel<1>), g, dim3(256), LDS, stream, a);
-    else hipLaunchKernelGGL((linear_f16x3_kernel<0>), g, dim3(256), LDS, stream, a);
-    return check_launch("linear_f16x3_kernel");
+    if (reg_staged) {
+        if (stage_a) hipLaunchKernelGGL((linear_f16x3_kernel<1>), g, dim3(256), LDS, stream, a);
+        else hipLaunchKernelGGL((linear_f16x3_kernel<0>), g, dim3(256), LDS, stream, a);
+        return check_launch("linear_f16x3_kernel");
+    }
+    if (stage_a) hipLaunchKernelGGL((linear_f16x3_dma_kernel<1>), g, dim3(256), LDS_DMA, stream, a);
+    else hipLaunchKernelGGL((linear_f16x3_dma_kernel<0>), g, dim3(256), LDS_DMA, stream, a);
+    return check_launch("linear_f16x3_dma_kernel");
 }
 
 }  // namespace phonlp
@@ -248,4 +434,17 @@ extern "C" int phonlp_linear_split(const void *Xp, const float *x_inv, const voi
     if (kind < 0 || kind > 3) return fail(PHONLP_ERR_SHAPE, "linear_split: kind must be 0..3");
     return launch_linear_f16x3(tags[kind], Xp, 4L * K16, x_inv, Wp, 4L * K16, w_inv, bias, Y, ldy, M, N, K16, relu, sentlens,
                                L, as_stream(stream), pad_bias);
+}
+
+extern "C" size_t phonlp_label_t4_bytes(int B, int L, int H, int O) {
+    if (B <= 0 || L <= 0 || H <= 0 || O <= 0) return 0;
+    return (size_t)(((long)B * L + 3) / 4 * 4) * (size_t)O * kp_of(H) * sizeof(float);
+}
+
+extern "C" int phonlp_label_stage_a_split(const void *X1p, const float *x1_inv, const void *Wbtp, const float *wbt_inv,
+                                          int B, int L, int H, int O, float *T4, void *stream) {
+    if (B <= 0 || L <= 0 || H <= 0 || O <= 0) return fail(PHONLP_ERR_SHAPE, "label_stage_a_split: bad argument");
+    const int KP = kp_of(H), K16 = (KP + 15) / 16 * 16;
+    return launch_linear_f16x3("linear:label_stage_a", X1p, 4L * K16, x1_inv, Wbtp, 4L * K16, wbt_inv, nullptr, T4, 0, B * L,
+                               O * KP, K16, 0, nullptr, 0, as_stream(stream), nullptr, 1);
 }

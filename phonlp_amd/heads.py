@@ -5,6 +5,7 @@ annotate_model.py:34-100) and packs them once into the layouts the kernels read.
 exposes the two forward seams (`tagger` ~ JointModel.tagger_forward, `parser` ~ JointModel.dep_forward,
 both starting AFTER the first-subword gather) and the decoders, everything staying on the device.
 """
+import os
 from dataclasses import dataclass
 from typing import Dict, Optional, Sequence, Union
 
@@ -218,6 +219,7 @@ class TaskHeads:
                                   w.upos_clf_b, w.emb_dep)
         # dep_hid is folded into the scorers' first layers (HeadWeights.from_state_dict): the scorers read `feat`
         split = ops.get_gemm_engine() == 2 and w.lab_Wbt_s is not None
+        rows4 = False
         B, Ld, D = feat.shape
         if split:  # engine 2: the large layers run on split images (one split pass per activation matrix)
             featp, feati = ops.split_rows(feat.view(B * Ld, D))
@@ -240,7 +242,11 @@ class TaskHeads:
             XF = ops.linear_split(featp, feati, w.lab_W12f_s[0], w.lab_W12f_s[1], w.lab_b12f, D, True, lens_d, Ld,
                                   w.lab_b12, 2)
             x1p, x1i = ops.split_rows(XF[:, :ops.kp(w.H)])
-            T = ops.linear_split(x1p, x1i, w.lab_Wbt_s[0], w.lab_Wbt_s[1], None, ops.kp(w.H), False, None, 0, None, 1)
+            rows4 = os.environ.get("PHONLP_ROWS4", "1") != "0"  # A/B switch: row-major T
+            if rows4:
+                T = ops.label_stage_a_split(x1p, x1i, w.lab_Wbt_s[0], w.lab_Wbt_s[1], B, Ld, w.H, w.O)  # T4 layout
+            else:
+                T = ops.linear_split(x1p, x1i, w.lab_Wbt_s[0], w.lab_Wbt_s[1], None, ops.kp(w.H), False, None, 0, None, 1)
         else:
             XF, T = ops.label_project(feat, w.lab_W12f, w.lab_b12f, w.lab_Wbt, w.H, w.O, lens_d, w.lab_b12)
         if join:
@@ -258,7 +264,10 @@ class TaskHeads:
             t.record_stream(fin)
         # labels only where annotate() reads them: at the decoded heads (ref annotate_model.py:263-266)
         with torch.cuda.stream(fin):
-            rels, _ = ops.label_at_heads(T, XF, heads, lens_d, w.H, w.O)
+            if split and rows4:
+                rels, _ = ops.label_at_heads_rows4(T, XF, heads, lens_d, w.H, w.O)
+            else:
+                rels, _ = ops.label_at_heads(T, XF, heads, lens_d, w.H, w.O)
             done = torch.cuda.Event()
             done.record(fin)
         return {"pos": tag["pos_pred"], "ner": ner, "heads": heads, "rels": rels, "mst_status": status,

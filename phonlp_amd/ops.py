@@ -346,3 +346,32 @@ def biaffine_arc_scores(XF: Tensor, B: int, L: int, Wbt: Tensor, H: int, n_score
     check(lib().phonlp_biaffine_arc_scores(_p(XF), B, L, H, n_scorers, int(use_lin), int(use_dist), _p(Wbt), _p(out),
                                            None, _p(ws), nb, _stream()), "phonlp_biaffine_arc_scores")
     return out
+
+
+@torch.library.custom_op("phonlp_amd::label_stage_a_split", mutates_args=())
+def label_stage_a_split(x1p: Tensor, x1_inv: Tensor, wbtp: Tensor, wbt_inv: Tensor, B: int, L: int, H: int,
+                        O: int) -> Tensor:
+    """Engine-2 stage A of the label scorer -> T4 (fp32, 'rows interleaved by 4': include/phonlp_heads.h)."""
+    _need(x1p, torch.uint8, "x1p")
+    _need(wbtp, torch.uint8, "wbtp")
+    if x1p.shape[0] != B * L or wbtp.shape[0] != O * kp(H) or x1p.shape[1] != wbtp.shape[1]:
+        raise ValueError("label_stage_a_split: split images do not match B, L, H, O")
+    T4 = torch.empty(lib().phonlp_label_t4_bytes(B, L, H, O) // 4, dtype=torch.float32, device=x1p.device)
+    check(lib().phonlp_label_stage_a_split(_p(x1p), _p(x1_inv), _p(wbtp), _p(wbt_inv), B, L, H, O, _p(T4), _stream()),
+          "phonlp_label_stage_a_split")
+    return T4
+
+
+@torch.library.custom_op("phonlp_amd::label_at_heads_rows4", mutates_args=())
+def label_at_heads_rows4(T4: Tensor, XF: Tensor, heads: Tensor, sentlens: Tensor, H: int, O: int) -> Tuple[Tensor, Tensor]:
+    """label_at_heads on the T4 image of label_stage_a_split."""
+    _need(T4, torch.float32, "T4")
+    _need(XF, torch.float32, "XF")
+    _need(heads, torch.int32, "heads")
+    _need(sentlens, torch.int32, "sentlens")
+    B, L = heads.shape
+    rels = torch.empty((B, L), dtype=torch.int32, device=T4.device)
+    best = torch.empty((B, L), dtype=torch.float32, device=T4.device)
+    check(lib().phonlp_label_at_heads_rows4(_p(T4), _p(XF), _p(heads), _p(sentlens), B, L, H, O, _p(rels), _p(best),
+                                            _stream()), "phonlp_label_at_heads_rows4")
+    return rels, best

@@ -483,6 +483,43 @@ def test_label_at_heads_matches_dense_label_scorer(dev, engine, B, L, H, O):
                 assert abs(float(col[got[b, i]]) - float(col[want[b, i]])) <= tol, (b, i)
 
 
+@pytest.mark.parametrize("B,L,H,O", [(5, 37, 24, 5), (8, 128, 400, 33), (3, 130, 400, 7)])
+def test_label_rows4_pair_matches_row_major(dev, B, L, H, O):
+    """Engine 2's stage A in the 'rows interleaved by 4' layout is the row-major stage A bit for bit (same loop,
+    different store), and label_at_heads_rows4 returns what label_at_heads returns on the same T: winning scores to
+    fp32 rounding (another summation order), relations equal except where the two best scores are that close."""
+    from phonlp_amd import HeadWeights, ops
+    from phonlp_amd import synthetic as S
+    sd = S.make_state_dict(64, 12, H, 7, O, 5, seed=L)
+    w = HeadWeights.from_state_dict(sd, dev)
+    g = torch.Generator().manual_seed(B * L + 1)
+    hidden = torch.randn(B, L, 64 + 12, generator=g).to(dev)
+    lens = torch.randint(2, L + 1, (B,), generator=g).to(torch.int32)
+    lens[0] = L
+    heads = torch.stack([torch.randint(0, int(n), (L,), generator=g) for n in lens]).to(torch.int32)
+    lens_d, heads_d = lens.to(dev), heads.to(dev)
+    KP = ops.kp(H)
+    XF, _ = ops.label_project(hidden, w.lab_W12, w.lab_b12, w.lab_Wbt, H, O)
+    x1p, x1i = ops.split_rows(XF[:, :KP])
+    wp, wi = w.lab_Wbt_s
+    T = ops.linear_split(x1p, x1i, wp, wi, None, KP, False, None, 0, None, 1)
+    T4 = ops.label_stage_a_split(x1p, x1i, wp, wi, B, L, H, O)
+    M = B * L
+    M4 = (M + 3) // 4 * 4
+    back = T4.view(M4 // 4, O * KP, 4).permute(0, 2, 1).reshape(M4, O * KP)[:M]
+    assert torch.equal(back, T)
+    r0, b0 = ops.label_at_heads(T, XF, heads_d, lens_d, H, O)
+    r4, b4 = ops.label_at_heads_rows4(T4, XF, heads_d, lens_d, H, O)
+    torch.testing.assert_close(b4, b0, rtol=1e-5, atol=1e-6)
+    diff = (r0 != r4)
+    if diff.any():  # only provable near-ties may differ: recompute both candidates' scores in float64
+        Tm = T.view(B, L, O, KP).double()
+        x2 = XF[:, KP:].view(B, L, KP).double()
+        for b, i in diff.nonzero().tolist():
+            sc = Tm[b, i] @ x2[b, heads[b, i]]
+            assert abs(sc[r0[b, i]] - sc[r4[b, i]]) <= 1e-5 * sc.abs().max()
+
+
 def test_streaming_batches_match_joined(dev):
     """annotate_batch(join=False) on back-to-back batches (tails on the finishing stream, next batch's GEMMs not
     waiting for the MST) gives exactly the outputs of the joined form."""
