@@ -19,6 +19,15 @@ struct MstArgs {
     long gmat_stride;   // doubles per sentence
     int B, L, pitch, lvl_stride;
     long long *dbg;  // diagnostic builds only (-DMST_STAMPS): 16 counters per sentence
+    // mst_wave.hip: single-root candidates shared between the workgroups of one launch (mst_share_bytes())
+    int32_t *ctr;          // [8]: started, first_done, q_tail, q_head  (zeroed per launch, with tasks and cand_left)
+    int32_t *tasks;        // [B*L] queue of (sentence*256 + candidate slot) + 1; 0 = not written yet
+    int32_t *cand_left;    // [B] candidates of the sentence still running
+    int32_t *cand_n;       // [B] number of candidates (bit 16: a decode hit the level limit)
+    int32_t *cand_root;    // [B][L] candidate roots, ascending
+    double *cand_score;    // [B][L]
+    uint32_t *cand_tree;   // [B][L][Lw] candidate trees, one byte per node, Lw = ceil(L/4) words
+    int max_waiters;       // workgroups allowed to wait for late candidates at one time (they hold a CU's LDS)
 };
 
 #ifdef MST_STAMPS
@@ -69,6 +78,9 @@ inline int mst_pitch(int L) { return L | 1; }
 
 // mst_wave.hip
 bool mst_wave_fits(int L);
-int launch_mst_wave(const MstArgs &a, hipStream_t stream);
+size_t mst_share_bytes(int B, int L);
+void mst_share_carve(MstArgs &a, void *base);
+size_t mst_share_zero_bytes(int B, int L);  // leading part of the region that every launch clears
+int launch_mst_wave(MstArgs a, hipStream_t stream);
 
 }  // namespace phonlp

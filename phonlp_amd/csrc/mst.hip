@@ -349,6 +349,7 @@ using namespace phonlp;
 extern "C" size_t phonlp_mst_ws_bytes(int B, int L) {
     size_t bytes = align_up((size_t)B * L * mst_lvl_stride(L) * sizeof(uint16_t), 256);
     if (!mst_fits_lds(L)) bytes += align_up((size_t)B * L * mst_pitch(L) * sizeof(double), 256);
+    if (mst_wave_fits(L)) bytes += mst_share_bytes(B, L);
     return bytes;
 }
 
@@ -380,7 +381,12 @@ extern "C" int phonlp_mst_one_root(const float *arc, const int32_t *sentlens, in
         attr_set = true;
     }
     ProfScope ps("mst", as_stream(stream));
-    if (mst_wave_fits(L) && !getenv("PHONLP_MST_BLOCKSYNC")) return launch_mst_wave(a, as_stream(stream));
+    if (mst_wave_fits(L) && !getenv("PHONLP_MST_BLOCKSYNC")) {
+        size_t off = align_up((size_t)B * L * a.lvl_stride * sizeof(uint16_t), 256);
+        if (!in_lds) off += align_up((size_t)B * L * a.pitch * sizeof(double), 256);
+        mst_share_carve(a, (char *)ws + off);
+        return launch_mst_wave(a, as_stream(stream));
+    }
     if (in_lds) {
         lds += (size_t)L * a.pitch * sizeof(double);
         hipLaunchKernelGGL(mst_kernel<true>, dim3(B), dim3(threads), lds, as_stream(stream), a);

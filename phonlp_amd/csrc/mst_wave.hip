@@ -15,6 +15,17 @@
 // members, their heads, and per outside node the two arg-max picks; the outside-node list is rebuilt from the
 // member list).  A level that does not fit spills to the caller's global workspace; its loads are slower, the
 // result is the same.
+//
+// Single-root retries (ref :137-169) are SHARED between the workgroups of a launch.  A sentence whose unconstrained
+// tree has r >= 2 children of ROOT needs r more decodes, one per candidate root; done by the owning workgroup alone
+// they made the stragglers (1 + r decodes) set the kernel's duration.  Here the owner pushes the r candidates on a
+// queue in global memory and every workgroup, once its own sentence is decoded, pops candidates -- of any sentence --
+// until the queue is empty.  Each candidate's score and tree go to global scratch; the workgroup that finishes a
+// sentence's LAST candidate picks the winner in candidate order with strict '>' (ref :159), so the result does not
+// depend on who decoded what.  A workgroup with nothing to pop leaves (default), or -- up to max_waiters of them --
+// waits for late pushes, and then only while every workgroup of the grid has started (all of them are then resident
+// and finish their first decode without needing its CU); if some have not started yet it exits, so the grid always
+// drains.
 #include "mst.h"
 
 namespace phonlp {
@@ -22,6 +33,39 @@ namespace phonlp {
 #define WFENCE() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
 
 enum { WS_NEXT = 0, WS_DONE, WS_COUNT = 8 };
+enum { CT_STARTED = 0, CT_FIRST_DONE, CT_Q_TAIL, CT_Q_HEAD, CT_WAITERS, CT_COUNT = 8 };
+
+size_t mst_share_zero_bytes(int B, int L) { return align_up(((size_t)CT_COUNT + B + (size_t)B * L) * sizeof(int32_t), 256); }
+size_t mst_share_bytes(int B, int L) {
+    const size_t Lw = (L + 3) / 4;
+    return mst_share_zero_bytes(B, L) + align_up((size_t)B * sizeof(int32_t), 256) +
+           align_up((size_t)B * L * sizeof(int32_t), 256) + align_up((size_t)B * L * sizeof(double), 256) +
+           align_up((size_t)B * L * Lw * sizeof(uint32_t), 256);
+}
+void mst_share_carve(MstArgs &a, void *base) {
+    char *p = (char *)base;
+    const size_t B = a.B, L = a.L, Lw = (L + 3) / 4;
+    a.ctr = (int32_t *)p;
+    a.cand_left = a.ctr + CT_COUNT;
+    a.tasks = a.cand_left + B;
+    p += mst_share_zero_bytes(a.B, a.L);
+    a.cand_n = (int32_t *)p;      p += align_up(B * sizeof(int32_t), 256);
+    a.cand_root = (int32_t *)p;   p += align_up(B * L * sizeof(int32_t), 256);
+    a.cand_score = (double *)p;   p += align_up(B * L * sizeof(double), 256);
+    a.cand_tree = (uint32_t *)p;
+}
+
+// device-scope loads that bypass the (non-coherent) per-CU cache: data another workgroup published
+__device__ __forceinline__ int ld_i32(const int32_t *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned ld_u32(const uint32_t *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_f64(const double *p) {
+    return __longlong_as_double(__hip_atomic_load(reinterpret_cast<const long long *>(p), __ATOMIC_RELAXED,
+                                                  __HIP_MEMORY_SCOPE_AGENT));
+}
 
 struct WaveLayout {
     size_t off_edge, off_int, off_stack, total;
@@ -95,17 +139,12 @@ __device__ __forceinline__ int row_argmax16_cols(const double *S, int pitch, int
 template <int NPL>
 __global__ __launch_bounds__(256) void mst_wave_kernel(MstArgs a, int stack_cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int wg = blockIdx.x, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6, sub = lane & 15;
-    const int L = a.L, pitch = a.pitch;
-    int l = a.sentlens[b];
-    if (l > L) l = L;
-    int32_t *hout = a.heads + (long)b * L;
-    for (int t = tid; t < L; t += 256) hout[t] = 0;
-    if (l <= 1) {
-        if (tid == 0) a.status[b] = l == 1 ? PHONLP_MST_NO_FINITE_TREE : PHONLP_MST_OK;
-        return;
-    }
+    const int L = a.L, pitch = a.pitch, Lw = (L + 3) >> 2;
+    if (tid == 0) atomicAdd(&a.ctr[CT_STARTED], 1);
+    int b = wg, slot = -1, root = -1;  // current task: sentence, candidate slot (-1 = the unconstrained decode)
+    bool waiting = false;              // thread 0: this workgroup has taken one of the waiter places
 #ifdef MST_STAMPS
     long long stamp_acc[16] = {0};
     long long stamp_t = clock64();
@@ -118,17 +157,26 @@ __global__ __launch_bounds__(256) void mst_wave_kernel(MstArgs a, int stack_cap)
     int *besttree = tree0 + L, *lvl_n = besttree + L, *lvl_c = lvl_n + L, *lvl_off = lvl_c + L;
     int *sc = lvl_off + L;
     unsigned char *lstack = reinterpret_cast<unsigned char *>(sc + WS_COUNT);
-    unsigned char *gstack = reinterpret_cast<unsigned char *>(a.stack + (long)b * a.stack_stride);
+    unsigned char *gstack = reinterpret_cast<unsigned char *>(a.stack + (long)wg * a.stack_stride);  // per WORKER
     const int gstride = a.lvl_stride * 2;  // bytes per spilled level (>= 2n)
-    const float *arc = a.arc + (long)b * L * L;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 #define SM(r, c) S[(long)(r) * pitch + (c)]
 
-    int root = -1;
-    double best_score = NEG_INF_D;  // wave 0 only
-    int have_best = 0, err = 0;
-
-    for (;;) {
+    for (;;) {  // one task per trip: first this workgroup's own sentence, then candidates popped from the queue
+        int err = 0;
+        int l = a.sentlens[b];
+        if (l > L) l = L;
+        const float *arc = a.arc + (long)b * L * L;
+        int32_t *hout = a.heads + (long)b * L;
+        bool skip = false;
+        if (slot < 0) {
+            for (int t = tid; t < L; t += 256) hout[t] = 0;
+            if (l <= 1) {
+                if (tid == 0) a.status[b] = l == 1 ? PHONLP_MST_NO_FINITE_TREE : PHONLP_MST_OK;
+                skip = true;  // block-uniform
+            }
+        }
+        if (!skip) {
         // ---- whole workgroup: load + edit the matrix (ref :136, :143-149, :55-57), level-0 arg-max (ref :58)
         for (int idx = tid; idx < l * l; idx += 256) {
             const int i = idx / l, j = idx - i * l;
@@ -412,36 +460,50 @@ __global__ __launch_bounds__(256) void mst_wave_kernel(MstArgs a, int stack_cap)
             if (tid == 0) stamp_acc[11] += 1;
 #endif
             // ------------------------------------------------------------------ single-root logic (ref :137-169)
-            int next = INT_MAX, done = 0;
-            if (err) {
-                done = 2;
-            } else if (root < 0) {
+            if (slot < 0) {
+                // the unconstrained tree: done if ROOT has exactly one child, else its children become candidates
                 int nroot = 0;
+                if (!err) {
 #pragma unroll
-                for (int q = 0; q < NPL; ++q) {
-                    const int v = lane + 64 * q;
-                    const int hv = v < l ? cur[v] : -1;
-                    if (v < l) tree0[v] = hv;
-                    const unsigned long long bal = __ballot(v >= 1 && v < l && hv == 0);
-                    if (bal && next == INT_MAX) next = 64 * q + __builtin_ctzll(bal);
-                    nroot += __popcll(bal);
+                    for (int q = 0; q < NPL; ++q) {
+                        const int v = lane + 64 * q;
+                        const int isr = (v >= 1 && v < l && cur[v] == 0) ? 1 : 0;
+                        const unsigned long long bal = __ballot(isr);
+                        if (isr) a.cand_root[(long)b * L + nroot + __popcll(bal & lt_mask)] = v;  // ascending
+                        nroot += __popcll(bal);
+                    }
                 }
-                if (nroot == 1) {
+                if (err) {
+                    if (lane == 0) a.status[b] = 2;
+                } else if (nroot == 1) {
 #pragma unroll
                     for (int q = 0; q < NPL; ++q) {
                         const int v = lane + 64 * q;
                         if (v < l) hout[v] = cur[v];
                     }
                     if (lane == 0) a.status[b] = PHONLP_MST_OK;
-                    done = 1;
+                } else if (nroot == 0) {
+                    if (lane == 0) a.status[b] = PHONLP_MST_NO_FINITE_TREE;
+                } else {
+                    if (lane == 0) {
+                        a.cand_n[b] = nroot;
+                        a.cand_left[b] = nroot;
+                    }
+                    __threadfence();  // candidate roots and counts before the queue entries that point at them
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(&a.ctr[CT_Q_TAIL], nroot);
+                    base = __shfl(base, 0);
+                    for (int j = lane; j < nroot; j += 64)
+                        __hip_atomic_store(&a.tasks[base + j], b * 256 + j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             } else {
-                int finite = 1;
+                // a candidate: its score (ref :155-158) and tree go to global scratch
+                int finite = err ? 0 : 1;
 #pragma unroll
                 for (int q = 0; q < NPL; ++q) {
                     const int i = lane + 64 * q;
                     double v = 0.0;
-                    if (i < l) {
+                    if (i < l && !err) {
                         const int j = cur[i];
                         if (i == 0 || i == root) v = j == 0 ? 0.0 : NEG_INF_D;
                         else if (j == 0 || j == i) v = NEG_INF_D;
@@ -453,53 +515,104 @@ __global__ __launch_bounds__(256) void mst_wave_kernel(MstArgs a, int stack_cap)
                 WFENCE();
                 double score = NEG_INF_D;
                 if (finite) score = np_sum<4>(edge, l) + (double)arc[(long)root * L];
-                if (score > best_score) {  // strict: the first best candidate wins (ref :159)
-                    best_score = score;
-                    have_best = 1;
+                uint32_t *tr = a.cand_tree + ((long)b * L + slot) * Lw;
+                for (int wd = lane; wd < Lw; wd += 64) {
+                    unsigned pk = 0;
 #pragma unroll
-                    for (int q = 0; q < NPL; ++q) {
-                        const int v = lane + 64 * q;
-                        if (v < l) besttree[v] = cur[v];
+                    for (int e = 0; e < 4; ++e) {
+                        const int v = 4 * wd + e;
+                        if (v < l && !err) pk |= (unsigned)(cur[v] & 0xFF) << (8 * e);
+                    }
+                    tr[wd] = pk;
+                }
+                if (lane == 0) {
+                    a.cand_score[(long)b * L + slot] = score;
+                    if (err) atomicOr(&a.cand_n[b], 0x10000);
+                }
+                __threadfence();  // this candidate's result before the count that may hand the sentence to a finisher
+                int left = 0;
+                if (lane == 0) left = atomicSub(&a.cand_left[b], 1);
+                left = __shfl(left, 0);
+                if (left == 1) {  // last candidate of the sentence: pick the winner in candidate order (ref :159)
+                    __threadfence();
+                    const int cn = ld_i32(&a.cand_n[b]);
+                    const int r = cn & 0xFFFF;
+                    double best = NEG_INF_D;
+                    int bj = -1;
+                    for (int j = 0; j < r; ++j) {
+                        const double sj = ld_f64(&a.cand_score[(long)b * L + j]);
+                        if (sj > best) { best = sj; bj = j; }
+                    }
+                    if (cn & 0x10000) {
+                        if (lane == 0) a.status[b] = 2;
+                    } else if (bj < 0) {
+                        if (lane == 0) a.status[b] = PHONLP_MST_NO_FINITE_TREE;
+                    } else {
+                        const uint32_t *bt = a.cand_tree + ((long)b * L + bj) * Lw;
+                        for (int wd = lane; wd < Lw; wd += 64) {
+                            const unsigned pk = ld_u32(&bt[wd]);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int v = 4 * wd + e;
+                                if (v < l) hout[v] = (pk >> (8 * e)) & 0xFF;
+                            }
+                        }
+                        if (lane == 0) a.status[b] = PHONLP_MST_OK;
                     }
                 }
-#pragma unroll
-                for (int q = 0; q < NPL; ++q) {
-                    const int v = lane + 64 * q;
-                    const unsigned long long bal = __ballot(v < l && v > root && tree0[v] == 0);
-                    if (bal && next == INT_MAX) next = 64 * q + __builtin_ctzll(bal);
-                }
             }
-            if (!done && next == INT_MAX) {  // candidates exhausted: emit the best tree (or report none)
-                if (have_best) {
-                    WFENCE();
-#pragma unroll
-                    for (int q = 0; q < NPL; ++q) {
-                        const int v = lane + 64 * q;
-                        if (v < l) hout[v] = besttree[v];
-                    }
-                    if (lane == 0) a.status[b] = PHONLP_MST_OK;
-                } else if (lane == 0) {
-                    a.status[b] = PHONLP_MST_NO_FINITE_TREE;
-                }
-                done = 1;
-            }
-            if (done == 2 && lane == 0) a.status[b] = 2;
-            if (lane == 0) { sc[WS_NEXT] = next; sc[WS_DONE] = done; }
             STAMP(8);
         }
         __syncthreads();
-#ifdef MST_STAMPS
-        if (tid == 0 && a.dbg)
-            for (int k = 0; k < 16; ++k) a.dbg[(long)b * 16 + k] = stamp_acc[k];
-#endif
-        if (sc[WS_DONE]) return;
-        root = sc[WS_NEXT];
+        }  // !skip
+        // ---- next task (thread 0 decides for the workgroup)
+        if (tid == 0) {
+            if (slot < 0) {
+                __threadfence();  // this sentence's pushes before the count that tells waiters no more are coming
+                atomicAdd(&a.ctr[CT_FIRST_DONE], 1);
+            }
+            int code = -1;
+            for (;;) {
+                const int h = ld_i32(&a.ctr[CT_Q_HEAD]), t = ld_i32(&a.ctr[CT_Q_TAIL]);
+                if (h < t) {
+                    if (atomicCAS(&a.ctr[CT_Q_HEAD], h, h + 1) == h) {
+                        int v;
+                        while ((v = ld_i32(&a.tasks[h])) == 0) __builtin_amdgcn_s_sleep(2);  // pusher is mid-store
+                        code = v - 1;
+                        break;
+                    }
+                    continue;
+                }
+                if (ld_i32(&a.ctr[CT_STARTED]) < a.B) break;  // not every workgroup is resident: never wait
+                if (!waiting) {  // a waiter holds its CU's LDS against the GEMMs of other streams: bounded number
+                    if (atomicAdd(&a.ctr[CT_WAITERS], 1) >= a.max_waiters) break;
+                    waiting = true;
+                }
+                if (ld_i32(&a.ctr[CT_FIRST_DONE]) >= a.B) {   // no push can follow; look once more, then leave
+                    if (ld_i32(&a.ctr[CT_Q_HEAD]) < ld_i32(&a.ctr[CT_Q_TAIL])) continue;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(32);
+            }
+            __threadfence();
+            sc[WS_NEXT] = code;
+        }
         __syncthreads();
+        const int code = sc[WS_NEXT];
+        __syncthreads();
+        if (code < 0) break;
+        b = code >> 8;
+        slot = code & 0xFF;
+        root = ld_i32(&a.cand_root[(long)b * L + slot]);
     }
+#ifdef MST_STAMPS
+    if (tid == 0 && a.dbg)
+        for (int k = 0; k < 16; ++k) a.dbg[(long)wg * 16 + k] = stamp_acc[k];
+#endif
 #undef SM
 }
 
-int launch_mst_wave(const MstArgs &a, hipStream_t stream) {
+int launch_mst_wave(MstArgs a, hipStream_t stream) {
     const WaveLayout w = wave_layout(a.L);
     static bool attr_set = false;
     if (!attr_set) {
@@ -509,6 +622,14 @@ int launch_mst_wave(const MstArgs &a, hipStream_t stream) {
             return fail(PHONLP_ERR_LAUNCH, "mst_one_root: cannot raise the dynamic LDS limit");
         attr_set = true;
     }
+    // Measured (B=256, L=128, tools/ab_waiters.sh): 0 waiters is best -- workgroups that pop whatever is queued when they
+    // finish and leave otherwise give 1.16 ms alone / 3.96 ms per bench step; 256 waiters 1.25 / 4.12 (the waiters'
+    // LDS keeps the GEMMs of the other streams off their CUs).
+    static const int waiters = getenv("PHONLP_MST_WAITERS") ? atoi(getenv("PHONLP_MST_WAITERS")) : 0;
+    a.max_waiters = waiters;
+    // the queue, its counters and the per-sentence candidate counts start at zero in every launch
+    if (hipMemsetAsync(a.ctr, 0, mst_share_zero_bytes(a.B, a.L), stream) != hipSuccess)
+        return fail(PHONLP_ERR_LAUNCH, "mst_one_root: cannot clear the candidate queue");
     if (a.L <= 64) hipLaunchKernelGGL(mst_wave_kernel<1>, dim3(a.B), dim3(256), w.total, stream, a, w.stack_cap);
     else if (a.L <= 128) hipLaunchKernelGGL(mst_wave_kernel<2>, dim3(a.B), dim3(256), w.total, stream, a, w.stack_cap);
     else hipLaunchKernelGGL(mst_wave_kernel<4>, dim3(a.B), dim3(256), w.total, stream, a, w.stack_cap);
