@@ -10,7 +10,7 @@ B=$GRAFT_REPO_ROOT/bench.py
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats --output-format csv -- python3 $B --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/stats.err || exit 1
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o fetch --output-format csv -- python3 $B --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/fetch.err || exit 1
 timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o write --output-format csv -- python3 $B --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/write.err || exit 1
-timeout -s KILL 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F32 -d $OUT/mfma -o mfma --output-format csv -- python3 $B --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/mfma.err || exit 1
+timeout -s KILL 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU_MFMA_MOPS_F32 -d $OUT/mfma -o mfma --output-format csv -- python3 $B --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/mfma.err || exit 1
 python3 - <<PY
 import csv, glob, json, collections
 out = "$OUT"
@@ -42,6 +42,7 @@ for k, c in sorted(acc.items()):
     mf.append({"kernel": k, "mfma_busy_cycles_per_launch": busy, "gpu_cycles_per_launch": gui,
                "mfma_pipe_util": busy / (1024.0 * gui),
                "mops_bf16": sum(c.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", [0])) / max(len(c.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", [0])), 1),
+               "mops_f16": sum(c.get("SQ_INSTS_VALU_MFMA_MOPS_F16", [0])) / max(len(c.get("SQ_INSTS_VALU_MFMA_MOPS_F16", [0])), 1),
                "mops_f32": sum(c.get("SQ_INSTS_VALU_MFMA_MOPS_F32", [0])) / max(len(c.get("SQ_INSTS_VALU_MFMA_MOPS_F32", [0])), 1)})
 stats = glob.glob(f"{out}/stats/**/*kernel_stats.csv", recursive=True)
 summary = {"_how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over python3 bench.py --steps 3 --warmup 1 "
