@@ -41,6 +41,9 @@ SIGNATURES = {
     "phonlp_label_t4_bytes": (_z, [_i, _i, _i, _i]),
     "phonlp_label_stage_a_split": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p]),
     "phonlp_label_at_heads_rows4": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p]),
+    "phonlp_label_kpc": (_i, [_i]),
+    "phonlp_label_at_heads_fused_ws_bytes": (_z, [_i, _i, _i, _i]),
+    "phonlp_label_at_heads_fused": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _z, _p]),
     "phonlp_gather_labels": (_i, [_p, _p, _p, _i, _i, _p, _p]),
     "phonlp_gather_first_subword": (_i, [_p, _p, _i, _p, _i, _i, _i, _i, _p, _p]),
     "phonlp_eval_counts": (_i, [_p] * 11 + [_i, _i, _i, _p, _p]),

@@ -15,7 +15,8 @@ namespace phonlp {
 
 int gemm_engine();
 int launch_linear(const char *tag, const float *X, long ldx, const float *W, long ldw, const float *bias, float *Y, long ldy, int M,
-                  int N, int K, int relu, const int32_t *sentlens, int L, hipStream_t stream, const float *pad_bias = nullptr);
+                  int N, int K, int relu, const int32_t *sentlens, int L, hipStream_t stream, const float *pad_bias = nullptr, int nbatch = 1,
+                  long bsx = 0, long bsw = 0, long bsy = 0);
 
 // ------------------------------------------------------------------------------------------ arc
 struct ArcArgs {
@@ -581,11 +582,10 @@ static int arc_from_features(const float *XF, float *T, int B, int L, int KP, in
                              const float *Wbt, float *arc_logp, float *raw_opt, hipStream_t st) {
     const int M = B * L;
     int rc;
-    for (int s = 0; s < S; ++s) {
-        rc = launch_linear("linear:arc_stage_a", XF + 2 * s * KP, (long)S * 2 * KP, Wbt + (long)s * KP * KP, KP, nullptr, T + s * KP,
-                           (long)S * KP, M, KP, KP, 0, nullptr, 0, st);
-        if (rc) return rc;
-    }
+    // stage A of the S scorers as ONE batched launch (item s: X1 of scorer s, its bilinear weight, its slice of T)
+    rc = launch_linear("linear:arc_stage_a", XF, (long)S * 2 * KP, Wbt, KP, nullptr, T, (long)S * KP, M, KP, KP, 0, nullptr, 0, st,
+                       nullptr, S, 2L * KP, (long)KP * KP, KP);
+    if (rc) return rc;
     ArcArgs a{T, XF, arc_logp, raw_opt, (long)S * KP, (long)S * 2 * KP, B, L, KP, S, 0, use_lin, use_dist};
     a.LP = (L + 31) / 32 * 32 + 1;
     const size_t lds = (size_t)(160 * PITCH + 32 * a.LP) * sizeof(float);

@@ -56,7 +56,8 @@ ProfScope::~ProfScope() {
 }
 
 int launch_linear(const char *tag, const float *X, long ldx, const float *W, long ldw, const float *bias, float *Y, long ldy, int M,
-                  int N, int K, int relu, const int32_t *sentlens, int L, hipStream_t stream, const float *pad_bias = nullptr);
+                  int N, int K, int relu, const int32_t *sentlens, int L, hipStream_t stream, const float *pad_bias = nullptr, int nbatch = 1,
+                  long bsx = 0, long bsw = 0, long bsy = 0);
 
 // One wavefront per token.  logits [M, U] (U <= 64) -> pos_pred, feat = [enc | softmax(logits) . emb].
 // ref annotate_model.py:138-146 / :177-183.

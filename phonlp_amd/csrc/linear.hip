@@ -30,6 +30,11 @@ namespace phonlp {
 // groups, so the Gx blocks of one XCD work on one compact patch of tiles sharing A and B panels.
 template <int BM, int BN, int WM, int WN, int TAG, int ENG>
 __global__ __launch_bounds__(WM *WN * 64, 2) void linear_kernel(LinearArgs a) {
+    if (gridDim.y > 1) {  // batched launch: item blockIdx.y
+        a.X += blockIdx.y * a.bsx;
+        a.W += blockIdx.y * a.bsw;
+        a.Y += blockIdx.y * a.bsy;
+    }
     constexpr int THREADS = WM * WN * 64;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int BUF = (BM + BN) * PITCH;
@@ -142,6 +147,11 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void linear_kernel(LinearArgs a) {
 // Loop per slab: split+store slab k | barrier | issue global loads of slab k+1 | MFMAs on slab k | barrier.
 template <int TAG>
 __global__ __launch_bounds__(256, 2) void linear_split_kernel(LinearArgs a) {
+    if (gridDim.y > 1) {  // batched launch: item blockIdx.y
+        a.X += blockIdx.y * a.bsx;
+        a.W += blockIdx.y * a.bsw;
+        a.Y += blockIdx.y * a.bsy;
+    }
     constexpr int BM = 128, BN = 128, WM = 2, WN = 2, TM = 2, TN = 2, THREADS = 256;
     constexpr int PLANE_A = BM * 64, PLANE_B = BN * 64;        // bytes
     constexpr int LDS_BYTES = 3 * PLANE_A + 3 * PLANE_B;       // 49152
@@ -264,6 +274,11 @@ __global__ __launch_bounds__(256, 2) void linear_split_kernel(LinearArgs a) {
 // clamped to K-4 for the load and zeroed before the split.
 template <int TAG, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void linear_split256_kernel(LinearArgs a) {
+    if (gridDim.y > 1) {  // batched launch: item blockIdx.y
+        a.X += blockIdx.y * a.bsx;
+        a.W += blockIdx.y * a.bsw;
+        a.Y += blockIdx.y * a.bsy;
+    }
     constexpr int BM = 256, BN = 128, WM = 2, WN = 2, TM = 4, TN = 2, SK = 16;
     constexpr int ROWS = BM + BN, PLANE = ROWS * 32, BUF = 3 * PLANE;
     static_assert(WM * WN * 32 * (TN * 32 + 4) * 4 <= 2 * BUF, "epilogue patch must fit");
@@ -761,28 +776,31 @@ static int persistent_grid(int ntiles) {
 // `pad_bias` is given, as act(pad_bias): that is what a following layer makes of an all-zero input row, used when
 // the layer that produced those zero rows has been folded into this one (heads.py: dep_hid folded into W1/W2).
 int launch_linear(const char *tag, const float *X, long ldx, const float *W, long ldw, const float *bias, float *Y, long ldy, int M,
-                  int N, int K, int relu, const int32_t *sentlens, int L, hipStream_t stream, const float *pad_bias) {
+                  int N, int K, int relu, const int32_t *sentlens, int L, hipStream_t stream, const float *pad_bias, int nbatch,
+                  long bsx, long bsw, long bsy) {
     if (!X || !W || !Y || M <= 0 || N <= 0 || K <= 0) return fail(PHONLP_ERR_SHAPE, "linear: bad argument");
     if ((K & 3) || (ldx & 3) || (ldw & 3) || ((uintptr_t)X & 15) || ((uintptr_t)W & 15))
         return fail(PHONLP_ERR_SHAPE, "linear: K, ldx, ldw must be multiples of 4 and X, W 16-byte aligned");
     if (sentlens && L <= 0) return fail(PHONLP_ERR_SHAPE, "linear: sentlens given but L <= 0");
     if (pad_bias && !sentlens) return fail(PHONLP_ERR_SHAPE, "linear: pad_bias needs sentlens");
     LinearArgs a{X, W, bias, pad_bias, Y, sentlens, ldx, ldw, ldy, M, N, K, L, relu, 0, 0};
+    if (nbatch < 1 || (nbatch > 1 && ((bsx & 3) || (bsw & 3)))) return fail(PHONLP_ERR_SHAPE, "linear: bad batch strides");
+    a.bsx = bsx; a.bsw = bsw; a.bsy = bsy;
     const bool stage_a = tag && !strcmp(tag, "linear:label_stage_a");
     ProfScope ps(tag, stream);
     a.num_m = ceil_div(M, 128);
     const int eng = gemm_engine();
     if (N <= 64) {
         a.num_n = ceil_div(N, 32);
-        const dim3 g(persistent_grid(a.num_m * a.num_n));
+        const dim3 g(persistent_grid(a.num_m * a.num_n), nbatch);
         if (eng) hipLaunchKernelGGL((linear_kernel<128, 32, 4, 1, 0, 1>), g, dim3(256), 0, stream, a);
         else hipLaunchKernelGGL((linear_kernel<128, 32, 4, 1, 0, 0>), g, dim3(256), 0, stream, a);
     } else {
         a.num_n = ceil_div(N, 128);
-        const dim3 g(persistent_grid(a.num_m * a.num_n));
+        const dim3 g(persistent_grid(a.num_m * a.num_n), nbatch);
         static const bool in_regs = getenv("PHONLP_X6_IN_REGS") != nullptr;  // A/B switch: split per fragment use
         static const bool small_tile = getenv("PHONLP_X6_TILE128") != nullptr;  // A/B switch: 128 x 128 split kernel
-        const dim3 g1(a.num_m * a.num_n);
+        const dim3 g1(a.num_m * a.num_n, nbatch);
         if (eng && !in_regs && !small_tile && M >= 1024 && K >= 8) {
             static bool attr_set = false;
             constexpr int LDS = 2 * 3 * 384 * 32;
@@ -793,7 +811,7 @@ int launch_linear(const char *tag, const float *X, long ldx, const float *W, lon
                 attr_set = true;
             }
             a.num_m = ceil_div(M, 256);
-            const dim3 g2(a.num_m * a.num_n);
+            const dim3 g2(a.num_m * a.num_n, nbatch);
             static const int abl = getenv("PHONLP_X6_ABLATION") ? atoi(getenv("PHONLP_X6_ABLATION")) : 0;  // timing only
             if (abl) {
                 const void *fns[] = {(const void *)linear_split256_kernel<0, 1>, (const void *)linear_split256_kernel<0, 2>,
@@ -861,7 +879,7 @@ extern "C" int phonlp_get_gemm_engine(void) { return gemm_engine(); }
 
 extern "C" int phonlp_linear(const float *X, int ldx, const float *W, int ldw, const float *bias, float *Y, int ldy,
                              int M, int N, int K, int relu, const int32_t *sentlens, int L, void *stream) {
-    return launch_linear("linear", X, ldx, W, ldw, bias, Y, ldy, M, N, K, relu, sentlens, L, as_stream(stream), nullptr);
+    return launch_linear("linear", X, ldx, W, ldw, bias, Y, ldy, M, N, K, relu, sentlens, L, as_stream(stream), nullptr, 1, 0, 0, 0);
 }
 
 extern "C" int phonlp_pack_scorer_linear(const float *W1, const float *b1, const float *W2, const float *b2, int H,

@@ -117,6 +117,97 @@ __device__ __forceinline__ void rows4_epilogue(f32x16 (&acc)[TM][TN], const Line
         }
 }
 
+// Labels-at-heads epilogue (mode 2): the tile of T = X1 . Wbt^T never leaves the chip.  Columns are (relation o,
+// head feature d2) with kpc (a multiple of 32) columns per relation, so each 32-column accumulator tile lies inside
+// one relation; every element is multiplied by the head's feature x2[hrow[row]][d2] and the 32 columns are summed
+// across the half-wave: P[col/32][row] is this tile's share of score[row][o].  A later pass adds the kpc/32 shares
+// of a relation in ascending order (label_reduce_kernel), so the sum has one fixed order: deterministic, and the
+// same whatever batch a sentence is decoded in.  8 values are summed per butterfly: three halving exchanges
+// (lanes trade value halves) and two plain ones; lane l of a half then holds the total of value (l >> 2) & 7.
+template <int TM, int TN>
+__device__ __forceinline__ void at_heads_epilogue(f32x16 (&acc)[TM][TN], const LinearArgs &a, int m0, int n0, int wm,
+                                                  int wn, int lane) {
+    const int half = lane >> 5, l32 = lane & 31;
+    const bool b4 = l32 & 16, b3 = l32 & 8, b2 = l32 & 4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int base = m0 + (wm * TM + i) * 32 + 4 * half;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {  // registers 8q .. 8q+7: rows base + (r&3) + 8*(r>>2)
+            long xoff[8];
+            float rs[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int r = 8 * q + e;
+                const int row = base + (r & 3) + 8 * (r >> 2);
+                const int hr = row < a.M ? a.hrow[row] : -1;
+                xoff[e] = hr >= 0 ? (long)hr * a.ldx2 : -1;
+                rs[e] = row < a.M ? a.row_scale[row] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + (wn * TN + j) * 32 + l32;
+                const int d2 = col % a.kpc;
+                const bool valid = col < a.N && d2 < a.kpx;
+                const float cs = valid ? a.col_scale[col] : 0.f;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float x = (valid && xoff[e] >= 0) ? a.x2[xoff[e] + d2] : 0.f;
+                    v[e] = acc[i][j][8 * q + e] * rs[e] * cs * x;
+                }
+                float k4[4], k2[2];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) k4[t] = (b4 ? v[4 + t] : v[t]) + __shfl_xor(b4 ? v[t] : v[4 + t], 16);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) k2[t] = (b3 ? k4[2 + t] : k4[t]) + __shfl_xor(b3 ? k4[t] : k4[2 + t], 8);
+                float k = (b2 ? k2[1] : k2[0]) + __shfl_xor(b2 ? k2[0] : k2[1], 4);
+                k += __shfl_xor(k, 2);
+                k += __shfl_xor(k, 1);
+                // lane l32 holds value e = 4*b4 + 2*b3 + b2; one lane in four stores it
+                const int e = (l32 >> 2) & 7, r = 8 * q + e;
+                const int row = base + (r & 3) + 8 * (r >> 2);
+                const int g = (n0 + (wn * TN + j) * 32) >> 5;
+                if ((l32 & 3) == 0 && row < a.M && g * 32 < a.N) a.P[(long)g * a.M + row] = k;
+            }
+        }
+    }
+}
+
+// hrow[m] = row of the head's features for word m = (b, i), 1 <= i < sentlens[b]; -1 elsewhere (ROOT, padding)
+__global__ void head_rows_kernel(const int32_t *heads, const int32_t *sentlens, int M, int L, int32_t *hrow) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const int b = m / L, i = m - b * L;
+    int v = -1;
+    if (i >= 1 && i < sentlens[b]) {
+        const int h = heads[m];
+        if (h >= 0 && h < L) v = b * L + h;
+    }
+    hrow[m] = v;
+}
+
+// rels[m] = argmax_o sum_{t < gpo} P[o*gpo + t][m] (shares added in ascending t; strict '>' in ascending o), 0 for
+// words without a label.
+__global__ void label_reduce_kernel(const float *P, const int32_t *hrow, int M, int O, int gpo, int32_t *rels,
+                                    float *best_opt) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    float bv = -INFINITY;
+    int bo = 0;
+    if (hrow[m] >= 0) {
+        for (int o = 0; o < O; ++o) {
+            float s = 0.f;
+            for (int t = 0; t < gpo; ++t) s += P[(long)(o * gpo + t) * M + m];
+            if (s > bv) { bv = s; bo = o; }
+        }
+    } else {
+        bv = 0.f;
+    }
+    rels[m] = bo;
+    if (best_opt) best_opt[m] = bv;
+}
+
 // 256 x 128 block tile, four waves of 128 x 64 (8 accumulator tiles), k16 stages, two 24 KB LDS buffers, one
 // barrier per stage; two blocks per CU cover each other's barriers.  a.X / a.W are the split images (row pitch
 // a.ldx / a.ldw BYTES), a.K = K16.  Per stage and wave: 12 ds_read_b128 feed 24 MFMAs; per thread 6 global
@@ -229,6 +320,10 @@ __global__ __launch_bounds__(256, 2) void linear_f16x3_kernel(LinearArgs a) {
         if (s + 2 < nst) load_stage(s + 2);
         mma_frags(f);
         lds_barrier();
+    }
+    if (a.rows4 == 2) {
+        at_heads_epilogue<TM, TN>(acc, a, m0, n0, wm, wn, lane);
+        return;
     }
     if (a.rows4) {
         rows4_epilogue<TM, TN>(acc, a, m0, n0, wm, wn, lane);
@@ -357,6 +452,10 @@ __global__ __launch_bounds__(256, 2) void linear_f16x3_dma_kernel(LinearArgs a) 
         if (t == 1234.5f) a.Y[tid] = t;
         return;
     }
+    if (a.rows4 == 2) {
+        at_heads_epilogue<TM, TN>(acc, a, m0, n0, wm, wn, lane);
+        return;
+    }
     if (a.rows4) {
         rows4_epilogue<TM, TN>(acc, a, m0, n0, wm, wn, lane);
         return;
@@ -366,8 +465,9 @@ __global__ __launch_bounds__(256, 2) void linear_f16x3_dma_kernel(LinearArgs a) 
 
 int launch_linear_f16x3(const char *tag, const void *Xp, long pitch_x, const float *x_inv, const void *Wp, long pitch_w,
                         const float *w_inv, const float *bias, float *Y, long ldy, int M, int N, int K16, int relu,
-                        const int32_t *sentlens, int L, hipStream_t stream, const float *pad_bias, int rows4 = 0) {
-    if (!Xp || !Wp || !x_inv || !w_inv || !Y || M <= 0 || N <= 0 || K16 <= 0)
+                        const int32_t *sentlens, int L, hipStream_t stream, const float *pad_bias, int rows4 = 0,
+                        const LinearArgs *at_heads = nullptr) {
+    if (!Xp || !Wp || !x_inv || !w_inv || (!Y && !at_heads) || M <= 0 || N <= 0 || K16 <= 0)
         return fail(PHONLP_ERR_SHAPE, "linear_split: bad argument");
     if ((K16 & 15) || (pitch_x & 15) || (pitch_w & 15) || pitch_x < 4L * K16 || pitch_w < 4L * K16 ||
         ((uintptr_t)Xp & 15) || ((uintptr_t)Wp & 15))
@@ -391,7 +491,12 @@ int launch_linear_f16x3(const char *tag, const void *Xp, long pitch_x, const flo
     static const int abl = getenv("PHONLP_X3_ABLATION") ? atoi(getenv("PHONLP_X3_ABLATION")) : 0;  // timing only
     a.dbg = abl;
     a.rows4 = rows4;
-    if (rows4 && (bias || sentlens || relu || ((uintptr_t)Y & 15)))
+    if (at_heads) {
+        a.rows4 = 2;
+        a.x2 = at_heads->x2; a.hrow = at_heads->hrow; a.P = at_heads->P; a.ldx2 = at_heads->ldx2;
+        a.kpc = at_heads->kpc; a.kpx = at_heads->kpx;
+    }
+    if (rows4 == 1 && (bias || sentlens || relu || ((uintptr_t)Y & 15)))
         return fail(PHONLP_ERR_SHAPE, "linear_split: the rows-by-4 output takes no bias / activation / padding mask");
     ProfScope ps(tag, stream);
     const dim3 g(a.num_m * a.num_n);
@@ -447,4 +552,38 @@ extern "C" int phonlp_label_stage_a_split(const void *X1p, const float *x1_inv, 
     const int KP = kp_of(H), K16 = (KP + 15) / 16 * 16;
     return launch_linear_f16x3("linear:label_stage_a", X1p, 4L * K16, x1_inv, Wbtp, 4L * K16, wbt_inv, nullptr, T4, 0, B * L,
                                O * KP, K16, 0, nullptr, 0, as_stream(stream), nullptr, 1);
+}
+
+/* Labels at the decoded heads with stage A fused in: T never reaches memory. */
+extern "C" int phonlp_label_kpc(int H) { return (kp_of(H) + 31) / 32 * 32; }
+
+extern "C" size_t phonlp_label_at_heads_fused_ws_bytes(int B, int L, int H, int O) {
+    if (B <= 0 || L <= 0 || H <= 0 || O <= 0) return 0;
+    const size_t M = (size_t)B * L;
+    return align_up(M * sizeof(int32_t), 256) + align_up((size_t)O * (phonlp_label_kpc(H) / 32) * M * sizeof(float), 256);
+}
+
+extern "C" int phonlp_label_at_heads_fused(const void *X1p, const float *x1_inv, const void *Wbtcp, const float *wbtc_inv,
+                                           const float *XF, const int32_t *heads, const int32_t *sentlens, int B, int L,
+                                           int H, int O, int32_t *rels, float *best_opt, void *ws, size_t ws_bytes,
+                                           void *stream) {
+    if (!X1p || !x1_inv || !Wbtcp || !wbtc_inv || !XF || !heads || !sentlens || !rels || B <= 0 || L <= 0 || H <= 0 || O <= 0)
+        return fail(PHONLP_ERR_SHAPE, "label_at_heads_fused: bad argument");
+    if (!ws || ws_bytes < phonlp_label_at_heads_fused_ws_bytes(B, L, H, O))
+        return fail(PHONLP_ERR_WORKSPACE, "label_at_heads_fused: workspace too small");
+    hipStream_t st = as_stream(stream);
+    const int M = B * L, KP = kp_of(H), K16 = (KP + 15) / 16 * 16, KPC = phonlp_label_kpc(H);
+    int32_t *hrow = (int32_t *)ws;
+    float *P = (float *)((char *)ws + align_up((size_t)M * sizeof(int32_t), 256));
+    hipLaunchKernelGGL(head_rows_kernel, dim3(ceil_div(M, 256)), dim3(256), 0, st, heads, sentlens, M, L, hrow);
+    int rc = check_launch("head_rows_kernel");
+    if (rc) return rc;
+    LinearArgs ah{};
+    ah.x2 = XF + KP; ah.ldx2 = 2L * KP; ah.hrow = hrow; ah.P = P; ah.kpc = KPC; ah.kpx = KP;
+    rc = launch_linear_f16x3("linear:label_stage_a", X1p, 4L * K16, x1_inv, Wbtcp, 4L * K16, wbtc_inv, nullptr, nullptr, 0, M,
+                             O * KPC, K16, 0, nullptr, 0, st, nullptr, 0, &ah);
+    if (rc) return rc;
+    ProfScope ps("label_reduce", st);
+    hipLaunchKernelGGL(label_reduce_kernel, dim3(ceil_div(M, 256)), dim3(256), 0, st, P, hrow, M, O, KPC / 32, rels, best_opt);
+    return check_launch("label_reduce_kernel");
 }

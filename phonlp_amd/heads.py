@@ -56,6 +56,7 @@ class HeadWeights:
     arc_W12f_s: Optional[tuple] = None
     lab_W12f_s: Optional[tuple] = None
     lab_Wbt_s: Optional[tuple] = None
+    lab_Wbtc_s: Optional[tuple] = None  # the same with every relation's rows padded to a multiple of 32 (fused form)
 
     @classmethod
     def from_state_dict(cls, sd: Dict[str, torch.Tensor], device="cuda", linearization=True, distance=True):
@@ -118,7 +119,16 @@ class HeadWeights:
             H=H, O=O, n_arc_scorers=n_arc, linearization=bool(linearization), distance=bool(distance),
             arc_W12f_s=tuple(ops.split_rows(arcf[0])), lab_W12f_s=tuple(ops.split_rows(labf[0])),
             lab_Wbt_s=tuple(ops.split_rows(lab[2])),
+            lab_Wbtc_s=tuple(ops.split_rows(cls._pad_relations(lab[2], H, O))),
         )
+
+    @staticmethod
+    def _pad_relations(Wbt: torch.Tensor, H: int, O: int) -> torch.Tensor:
+        """[O*KP, KP] -> [O*KPC, KP]: row o*KPC + d2 = row o*KP + d2, added rows zero (phonlp_label_at_heads_fused)."""
+        KP, KPC = ops.kp(H), ops.label_kpc(H)
+        out = torch.zeros((O, KPC, KP), dtype=Wbt.dtype, device=Wbt.device)
+        out[:, :KP] = Wbt.view(O, KP, KP)
+        return out.view(O * KPC, KP)
 
 
 class TaskHeads:
@@ -219,7 +229,7 @@ class TaskHeads:
                                   w.upos_clf_b, w.emb_dep)
         # dep_hid is folded into the scorers' first layers (HeadWeights.from_state_dict): the scorers read `feat`
         split = ops.get_gemm_engine() == 2 and w.lab_Wbt_s is not None
-        rows4 = False
+        rows4 = fused = False
         B, Ld, D = feat.shape
         if split:  # engine 2: the large layers run on split images (one split pass per activation matrix)
             featp, feati = ops.split_rows(feat.view(B * Ld, D))
@@ -243,7 +253,13 @@ class TaskHeads:
                                   w.lab_b12, 2)
             x1p, x1i = ops.split_rows(XF[:, :ops.kp(w.H)])
             rows4 = os.environ.get("PHONLP_ROWS4", "1") != "0"  # A/B switch: row-major T
-            if rows4:
+            # Fused form (stage A after the MST with the labels-at-heads contraction in its epilogue, T never stored):
+            # off by default -- measured 4.33 vs 4.02 ms per step joined (the MST is then exposed on the critical path)
+            # and 3.9-4.0 vs 3.95-3.98 streaming
+            fused = os.environ.get("PHONLP_LABEL_FUSED", "0") == "1"
+            if fused:
+                T = x1p  # stage A runs after the MST, inside label_at_heads_fused (T never reaches memory)
+            elif rows4:
                 T = ops.label_stage_a_split(x1p, x1i, w.lab_Wbt_s[0], w.lab_Wbt_s[1], B, Ld, w.H, w.O)  # T4 layout
             else:
                 T = ops.linear_split(x1p, x1i, w.lab_Wbt_s[0], w.lab_Wbt_s[1], None, ops.kp(w.H), False, None, 0, None, 1)
@@ -264,11 +280,14 @@ class TaskHeads:
             t.record_stream(fin)
         # labels only where annotate() reads them: at the decoded heads (ref annotate_model.py:263-266)
         with torch.cuda.stream(fin):
-            if split and rows4:
+            if split and fused:
+                x1i.record_stream(fin)
+                rels, _ = ops.label_at_heads_fused(x1p, x1i, w.lab_Wbtc_s[0], w.lab_Wbtc_s[1], XF, heads, lens_d, w.H, w.O)
+            elif split and rows4:
                 rels, _ = ops.label_at_heads_rows4(T, XF, heads, lens_d, w.H, w.O)
             else:
                 rels, _ = ops.label_at_heads(T, XF, heads, lens_d, w.H, w.O)
             done = torch.cuda.Event()
             done.record(fin)
         return {"pos": tag["pos_pred"], "ner": ner, "heads": heads, "rels": rels, "mst_status": status,
-                "stream": fin, "done": done}
+                "stream": fin, "done": done, "tag_done": tag_done, "tag_stream": s_tag}

@@ -48,6 +48,10 @@ def kp(H: int) -> int:
     return lib().phonlp_kp(H)
 
 
+def label_kpc(H: int) -> int:
+    return lib().phonlp_label_kpc(H)
+
+
 @torch.library.custom_op("phonlp_amd::linear", mutates_args=())
 def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor], relu: bool, sentlens: Optional[Tensor], L: int) -> Tensor:
     """y = act(x @ weight.T + bias); rows (b,i) with i >= sentlens[b] are zeroed when sentlens is given."""
@@ -375,3 +379,59 @@ def label_at_heads_rows4(T4: Tensor, XF: Tensor, heads: Tensor, sentlens: Tensor
     check(lib().phonlp_label_at_heads_rows4(_p(T4), _p(XF), _p(heads), _p(sentlens), B, L, H, O, _p(rels), _p(best),
                                             _stream()), "phonlp_label_at_heads_rows4")
     return rels, best
+
+
+@torch.library.custom_op("phonlp_amd::label_at_heads_fused", mutates_args=())
+def label_at_heads_fused(x1p: Tensor, x1_inv: Tensor, wbtcp: Tensor, wbtc_inv: Tensor, XF: Tensor, heads: Tensor,
+                         sentlens: Tensor, H: int, O: int) -> Tuple[Tensor, Tensor]:
+    """Stage A of the label scorer with the labels-at-heads contraction fused into its epilogue (engine 2):
+    -> (rels int32 [B,L], winning score [B,L]).  wbtcp: HeadWeights.lab_Wbtc_s (relation rows padded to 32)."""
+    _need(x1p, torch.uint8, "x1p")
+    _need(wbtcp, torch.uint8, "wbtcp")
+    _need(XF, torch.float32, "XF")
+    _need(heads, torch.int32, "heads")
+    _need(sentlens, torch.int32, "sentlens")
+    B, L = heads.shape
+    if x1p.shape[0] != B * L or wbtcp.shape[0] != O * lib().phonlp_label_kpc(H) or x1p.shape[1] != wbtcp.shape[1]:
+        raise ValueError("label_at_heads_fused: split images do not match B, L, H, O")
+    rels = torch.empty((B, L), dtype=torch.int32, device=XF.device)
+    best = torch.empty((B, L), dtype=torch.float32, device=XF.device)
+    nb = lib().phonlp_label_at_heads_fused_ws_bytes(B, L, H, O)
+    ws = _ws(nb, XF.device)
+    check(lib().phonlp_label_at_heads_fused(_p(x1p), _p(x1_inv), _p(wbtcp), _p(wbtc_inv), _p(XF), _p(heads),
+                                            _p(sentlens), B, L, H, O, _p(rels), _p(best), _p(ws), nb, _stream()),
+          "phonlp_label_at_heads_fused")
+    return rels, best
+
+
+@torch.library.custom_op("phonlp_amd::eval_counts_into", mutates_args=("counts",))
+def eval_counts_into(counts: Tensor, pos: Tensor, ner: Tensor, heads: Tensor, rels: Tensor, gold_pos: Tensor,
+                     gold_ner: Tensor, gold_head: Tensor, gold_rel: Tensor, lens_tag: Tensor, lens_dep: Tensor,
+                     mst_status: Optional[Tensor]) -> None:
+    """eval_counts ADDED to an existing int64[8] device vector (what the C entry point does: no zero-fill, no add)."""
+    for n, t in (("pos", pos), ("ner", ner), ("heads", heads), ("rels", rels), ("gold_pos", gold_pos),
+                 ("gold_ner", gold_ner), ("gold_head", gold_head), ("gold_rel", gold_rel), ("lens_tag", lens_tag),
+                 ("lens_dep", lens_dep)):
+        _need(t, torch.int32, n)
+    _need(counts, torch.int64, "counts")
+    if counts.numel() < 8:
+        raise ValueError("eval_counts_into: counts must hold 8 int64")
+    B, Lt = pos.shape
+    Ld = heads.shape[1]
+    check(lib().phonlp_eval_counts(_p(pos), _p(ner), _p(heads), _p(rels), _p(gold_pos), _p(gold_ner), _p(gold_head),
+                                   _p(gold_rel), _p(lens_tag), _p(lens_dep), _p(mst_status), B, Lt, Ld, _p(counts),
+                                   _stream()), "phonlp_eval_counts")
+
+
+@torch.library.custom_op("phonlp_amd::ner_entity_counts_into", mutates_args=("counts",))
+def ner_entity_counts_into(counts: Tensor, pred: Tensor, gold: Tensor, sentlens: Tensor, tag_kind: Tensor,
+                           tag_type: Tensor) -> None:
+    """ner_entity_counts ADDED to an existing int64[3] device vector."""
+    for t, n in ((pred, "pred"), (gold, "gold"), (sentlens, "sentlens"), (tag_kind, "tag_kind"), (tag_type, "tag_type")):
+        _need(t, torch.int32, n)
+    _need(counts, torch.int64, "counts")
+    if counts.numel() < 3:
+        raise ValueError("ner_entity_counts_into: counts must hold 3 int64")
+    B, L = pred.shape
+    check(lib().phonlp_ner_entity_counts(_p(pred), _p(gold), _p(sentlens), _p(tag_kind), _p(tag_type), B, L,
+                                         tag_kind.numel(), _p(counts), _stream()), "phonlp_ner_entity_counts")

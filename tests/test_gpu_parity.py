@@ -510,14 +510,17 @@ def test_label_rows4_pair_matches_row_major(dev, B, L, H, O):
     assert torch.equal(back, T)
     r0, b0 = ops.label_at_heads(T, XF, heads_d, lens_d, H, O)
     r4, b4 = ops.label_at_heads_rows4(T4, XF, heads_d, lens_d, H, O)
-    torch.testing.assert_close(b4, b0, rtol=1e-5, atol=1e-6)
-    diff = (r0 != r4)
-    if diff.any():  # only provable near-ties may differ: recompute both candidates' scores in float64
-        Tm = T.view(B, L, O, KP).double()
-        x2 = XF[:, KP:].view(B, L, KP).double()
-        for b, i in diff.nonzero().tolist():
-            sc = Tm[b, i] @ x2[b, heads[b, i]]
-            assert abs(sc[r0[b, i]] - sc[r4[b, i]]) <= 1e-5 * sc.abs().max()
+    # ... and the fused form (stage A + contraction in one kernel, T never stored) gives the same again
+    rf, bf = ops.label_at_heads_fused(x1p, x1i, w.lab_Wbtc_s[0], w.lab_Wbtc_s[1], XF, heads_d, lens_d, H, O)
+    for rx, bx in ((r4, b4), (rf, bf)):
+        torch.testing.assert_close(bx, b0, rtol=1e-5, atol=1e-5)
+        diff = (r0 != rx)
+        if diff.any():  # only provable near-ties may differ: recompute both candidates' scores in float64
+            Tm = T.view(B, L, O, KP).double()
+            x2 = XF[:, KP:].view(B, L, KP).double()
+            for b, i in diff.nonzero().tolist():
+                sc = Tm[b, i] @ x2[b, heads[b, i]]
+                assert abs(sc[r0[b, i]] - sc[rx[b, i]]) <= 1e-5 * sc.abs().max()
 
 
 def test_streaming_batches_match_joined(dev):
