@@ -113,6 +113,14 @@ int phonlp_pos_head(const float *enc, int ld_enc, const int32_t *sentlens, int B
                     int H, int U, int TE, float *feat, int32_t *pos_pred, float *upos_logits,
                     void *ws, size_t ws_bytes, void *stream);
 
+/* The same head writing the feat rows as an engine-2 split image (feat_planes: phonlp_split_bytes(B*L, E+TE) bytes,
+ * feat_inv_scale [B*L]; identical to phonlp_split_rows of feat) for phonlp_linear_split, so no split pass over feat is
+ * needed; the fp32 feat itself is optional (feat_opt may be NULL). */
+int phonlp_pos_head_split(const float *enc, int ld_enc, const int32_t *sentlens, int B, int L, int E,
+                          const float *Whid, const float *bhid, const float *Wclf, const float *bclf, const float *emb,
+                          int H, int U, int TE, float *feat_opt, void *feat_planes, float *feat_inv_scale,
+                          int32_t *pos_pred, float *upos_logits, void *ws, size_t ws_bytes, void *stream);
+
 /* NER emissions -- annotate_model.py:149-150: logits[B,L,T] = pad(relu(feat . Wner^T + bner)). */
 int phonlp_ner_emission(const float *feat, int D, const int32_t *sentlens, int B, int L,
                         const float *Wner, const float *bner, int T, float *logits, void *stream);

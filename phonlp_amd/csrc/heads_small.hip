@@ -60,17 +60,31 @@ int launch_linear(const char *tag, const float *X, long ldx, const float *W, lon
                   long bsx = 0, long bsw = 0, long bsy = 0);
 
 // One wavefront per token.  logits [M, U] (U <= 64) -> pos_pred, feat = [enc | softmax(logits) . emb].
-// ref annotate_model.py:138-146 / :177-183.
+// ref annotate_model.py:138-146 / :177-183.  The row is assembled in this wave's LDS buffer; from there it goes out as
+// the fp32 feat row (feat != NULL) and / or as its engine-2 split image (planes != NULL: the arithmetic of
+// split_rows_kernel, linear_f16x3.hip, so the large layers that follow need no split pass over feat).
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+
 __global__ __launch_bounds__(256) void pos_tail_kernel(const float *enc, long ld_enc, const float *logits,
                                                        const float *emb, const int32_t *sentlens, int M, int L, int E,
-                                                       int U, int TE, float *feat, int32_t *pos_pred) {
+                                                       int U, int TE, float *feat, int32_t *pos_pred,
+                                                       unsigned char *planes, float *inv_scale) {
+    extern __shared__ __attribute__((aligned(16))) float rows[];
     const int lane = threadIdx.x & 63;
     const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (tok >= M) return;
+    const int D = E + TE, K16 = (D + 15) / 16 * 16;
+    float *row = rows + (threadIdx.x >> 6) * K16;
     const int b = tok / L, i = tok % L;
-    float *frow = feat + (long)tok * (E + TE);
+    float *frow = feat ? feat + (long)tok * D : nullptr;
+    unsigned char *prow = planes ? planes + (long)tok * K16 * 4 : nullptr;
     if (i >= sentlens[b]) {  // padding: pad_packed_sequence zeros, arg-max of a zero row = 0
-        for (int c = lane; c < E + TE; c += 64) frow[c] = 0.f;
+        if (frow)
+            for (int c = lane * 4; c < D; c += 256) *reinterpret_cast<float4 *>(frow + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (prow) {
+            for (int c = lane * 16; c < K16 * 4; c += 1024) *reinterpret_cast<uint4 *>(prow + c) = make_uint4(0, 0, 0, 0);
+            if (lane == 0) inv_scale[tok] = 1.f;
+        }
         if (pos_pred && lane == 0) pos_pred[tok] = 0;
         return;
     }
@@ -89,13 +103,43 @@ __global__ __launch_bounds__(256) void pos_tail_kernel(const float *enc, long ld
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     p = p / s;
+    unsigned mx = 0;
     for (int d = lane; d < TE; d += 64) {
         float acc = 0.f;
         for (int u = 0; u < U; ++u) acc += __shfl(p, u) * emb[u * TE + d];
-        frow[E + d] = acc;
+        row[E + d] = acc;
+        mx = max(mx, __float_as_uint(acc) & 0x7FFFFFFFu);
     }
+    for (int c = D + lane; c < K16; c += 64) row[c] = 0.f;
     const float *erow = enc + (long)tok * ld_enc;
-    for (int c = lane * 4; c < E; c += 256) *reinterpret_cast<float4 *>(frow + c) = *reinterpret_cast<const float4 *>(erow + c);
+    for (int c = lane * 4; c < E; c += 256) {
+        const float4 v = *reinterpret_cast<const float4 *>(erow + c);
+        *reinterpret_cast<float4 *>(row + c) = v;
+        mx = max(max(mx, __float_as_uint(v.x) & 0x7FFFFFFFu), max(__float_as_uint(v.y) & 0x7FFFFFFFu,
+                 max(__float_as_uint(v.z) & 0x7FFFFFFFu, __float_as_uint(v.w) & 0x7FFFFFFFu)));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (frow)
+        for (int c = lane * 4; c < D; c += 256) *reinterpret_cast<float4 *>(frow + c) = *reinterpret_cast<const float4 *>(row + c);
+    if (prow) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
+        int Ex = (int)(mx >> 23);
+        Ex = Ex < 16 ? 16 : (Ex > 254 ? 254 : Ex);
+        const float scale = __uint_as_float((unsigned)(268 - Ex) << 23);
+        if (lane == 0) inv_scale[tok] = __uint_as_float((unsigned)(Ex - 14) << 23);
+        for (int g = lane; g * 8 < K16; g += 64) {
+            h16x8 h, l;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float sv = row[g * 8 + e] * scale;
+                h[e] = (_Float16)sv;
+                l[e] = (_Float16)(sv - (float)h[e]);
+            }
+            *reinterpret_cast<h16x8 *>(prow + g * 32) = h;
+            *reinterpret_cast<h16x8 *>(prow + g * 32 + 16) = l;
+        }
+    }
 }
 
 }  // namespace phonlp
@@ -148,15 +192,17 @@ extern "C" size_t phonlp_pos_head_ws_bytes(int B, int L, int E, int H, int U, in
     return align_up(M * H * sizeof(float), 256) + align_up(M * U * sizeof(float), 256);
 }
 
-extern "C" int phonlp_pos_head(const float *enc, int ld_enc, const int32_t *sentlens, int B, int L, int E,
-                               const float *Whid, const float *bhid, const float *Wclf, const float *bclf,
-                               const float *emb, int H, int U, int TE, float *feat, int32_t *pos_pred,
-                               float *upos_logits, void *ws, size_t ws_bytes, void *stream) {
-    if (!enc || !sentlens || !Whid || !bhid || !Wclf || !bclf || !emb || !feat || B <= 0 || L <= 0)
+static int pos_head_impl(const float *enc, int ld_enc, const int32_t *sentlens, int B, int L, int E, const float *Whid,
+                         const float *bhid, const float *Wclf, const float *bclf, const float *emb, int H, int U, int TE,
+                         float *feat, int32_t *pos_pred, float *upos_logits, void *feat_planes, float *feat_inv_scale,
+                         void *ws, size_t ws_bytes, void *stream) {
+    if (!enc || !sentlens || !Whid || !bhid || !Wclf || !bclf || !emb || (!feat && !feat_planes) || B <= 0 || L <= 0)
         return fail(PHONLP_ERR_SHAPE, "pos_head: bad argument");
     if (U > 64 || U <= 0) return fail(PHONLP_ERR_UNSUPPORTED, "pos_head: needs 1 <= U <= 64 (one lane per tag)");
-    if ((E & 3) || (H & 3) || ((E + TE) & 3) || (ld_enc & 3) || ((uintptr_t)feat & 15))
+    if ((E & 3) || (H & 3) || ((E + TE) & 3) || (ld_enc & 3) || ((uintptr_t)feat & 15) || ((uintptr_t)feat_planes & 15))
         return fail(PHONLP_ERR_SHAPE, "pos_head: E, H, E+TE, ld_enc must be multiples of 4 and feat 16-byte aligned");
+    if ((feat_planes != nullptr) != (feat_inv_scale != nullptr))
+        return fail(PHONLP_ERR_SHAPE, "pos_head: feat_planes and feat_inv_scale go together");
     if (!ws || ws_bytes < phonlp_pos_head_ws_bytes(B, L, E, H, U, TE))
         return fail(PHONLP_ERR_WORKSPACE, "pos_head: workspace too small");
     hipStream_t st = as_stream(stream);
@@ -167,10 +213,31 @@ extern "C" int phonlp_pos_head(const float *enc, int ld_enc, const int32_t *sent
     if (rc) return rc;
     rc = launch_linear("linear:upos_clf", hid, H, Wclf, H, bclf, logits, U, M, U, H, 0, sentlens, L, st);
     if (rc) return rc;
+    const size_t lds = 4 * (size_t)((E + TE + 15) / 16 * 16) * sizeof(float);
+    if (lds > 64 * 1024) return fail(PHONLP_ERR_UNSUPPORTED, "pos_head: E + TE too large for the row buffers");
     ProfScope ps("pos_tail", st);
-    hipLaunchKernelGGL(pos_tail_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, st, enc, (long)ld_enc, logits, emb, sentlens,
-                       M, L, E, U, TE, feat, pos_pred);
+    hipLaunchKernelGGL(pos_tail_kernel, dim3(ceil_div(M, 4)), dim3(256), lds, st, enc, (long)ld_enc, logits, emb, sentlens,
+                       M, L, E, U, TE, feat, pos_pred, (unsigned char *)feat_planes, feat_inv_scale);
     return check_launch("pos_tail_kernel");
+}
+
+extern "C" int phonlp_pos_head(const float *enc, int ld_enc, const int32_t *sentlens, int B, int L, int E,
+                               const float *Whid, const float *bhid, const float *Wclf, const float *bclf,
+                               const float *emb, int H, int U, int TE, float *feat, int32_t *pos_pred,
+                               float *upos_logits, void *ws, size_t ws_bytes, void *stream) {
+    if (!feat) return fail(PHONLP_ERR_SHAPE, "pos_head: bad argument");
+    return pos_head_impl(enc, ld_enc, sentlens, B, L, E, Whid, bhid, Wclf, bclf, emb, H, U, TE, feat, pos_pred, upos_logits,
+                         nullptr, nullptr, ws, ws_bytes, stream);
+}
+
+extern "C" int phonlp_pos_head_split(const float *enc, int ld_enc, const int32_t *sentlens, int B, int L, int E,
+                                     const float *Whid, const float *bhid, const float *Wclf, const float *bclf,
+                                     const float *emb, int H, int U, int TE, float *feat_opt, void *feat_planes,
+                                     float *feat_inv_scale, int32_t *pos_pred, float *upos_logits, void *ws,
+                                     size_t ws_bytes, void *stream) {
+    if (!feat_planes) return fail(PHONLP_ERR_SHAPE, "pos_head_split: feat_planes is required");
+    return pos_head_impl(enc, ld_enc, sentlens, B, L, E, Whid, bhid, Wclf, bclf, emb, H, U, TE, feat_opt, pos_pred,
+                         upos_logits, feat_planes, feat_inv_scale, ws, ws_bytes, stream);
 }
 
 extern "C" int phonlp_ner_emission(const float *feat, int D, const int32_t *sentlens, int B, int L, const float *Wner,

@@ -225,18 +225,19 @@ class TaskHeads:
             tag_done = torch.cuda.Event()
             tag_done.record(s_tag)
         # parser chain up to the arc log-probs on the main stream
-        feat, _, _ = ops.pos_head(enc_dep.contiguous(), lens_d, w.upos_hid_w, w.upos_hid_b, w.upos_clf_w,
-                                  w.upos_clf_b, w.emb_dep)
-        # dep_hid is folded into the scorers' first layers (HeadWeights.from_state_dict): the scorers read `feat`
+        B, Ld, D = enc_dep.shape[0], enc_dep.shape[1], enc_dep.shape[2] + w.emb_dep.shape[1]
         split = ops.get_gemm_engine() == 2 and w.lab_Wbt_s is not None
         rows4 = fused = False
-        B, Ld, D = feat.shape
-        if split:  # engine 2: the large layers run on split images (one split pass per activation matrix)
-            featp, feati = ops.split_rows(feat.view(B * Ld, D))
+        # dep_hid is folded into the scorers' first layers (HeadWeights.from_state_dict): the scorers read `feat`
+        if split:  # engine 2: the large layers run on split images; the POS head's tail writes feat as one directly
+            featp, feati, _, _, _ = ops.pos_head_split(enc_dep.contiguous(), lens_d, w.upos_hid_w, w.upos_hid_b,
+                                                       w.upos_clf_w, w.upos_clf_b, w.emb_dep, False)
             XFa = ops.linear_split(featp, feati, w.arc_W12f_s[0], w.arc_W12f_s[1], w.arc_b12f, D, True, lens_d, Ld,
                                    w.arc_b12, 3)
             arc_logp = ops.biaffine_arc_scores(XFa, B, Ld, w.arc_Wbt, w.H, w.n_arc_scorers, w.linearization, w.distance)
         else:
+            feat, _, _ = ops.pos_head(enc_dep.contiguous(), lens_d, w.upos_hid_w, w.upos_hid_b, w.upos_clf_w,
+                                      w.upos_clf_b, w.emb_dep)
             arc_logp, _ = ops.deep_biaffine_arc(feat, w.arc_W12f, w.arc_b12f, w.arc_Wbt, w.H, w.n_arc_scorers,
                                                 w.linearization, w.distance, False, lens_d, w.arc_b12)
         arc_done = torch.cuda.Event()

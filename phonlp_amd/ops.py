@@ -435,3 +435,27 @@ def ner_entity_counts_into(counts: Tensor, pred: Tensor, gold: Tensor, sentlens:
     B, L = pred.shape
     check(lib().phonlp_ner_entity_counts(_p(pred), _p(gold), _p(sentlens), _p(tag_kind), _p(tag_type), B, L,
                                          tag_kind.numel(), _p(counts), _stream()), "phonlp_ner_entity_counts")
+
+
+@torch.library.custom_op("phonlp_amd::pos_head_split", mutates_args=())
+def pos_head_split(enc: Tensor, sentlens: Tensor, Whid: Tensor, bhid: Tensor, Wclf: Tensor, bclf: Tensor, emb: Tensor,
+                   want_feat: bool) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor]:
+    """pos_head whose feat rows come out as an engine-2 split image: -> (planes uint8 [B*L, 4*K16], inv_scale [B*L],
+    pos_pred int32 [B,L], upos_logits [B,L,U], feat [B,L,E+TE] or an empty tensor)."""
+    _need(enc, torch.float32, "enc")
+    _need(sentlens, torch.int32, "sentlens")
+    B, L, E = enc.shape
+    H, U, TE = Whid.shape[0], Wclf.shape[0], emb.shape[1]
+    dev = enc.device
+    D = E + TE
+    planes = torch.empty((B * L, lib().phonlp_split_bytes(1, D)), dtype=torch.uint8, device=dev)
+    inv = torch.empty((B * L,), dtype=torch.float32, device=dev)
+    feat = torch.empty((B, L, D), dtype=torch.float32, device=dev) if want_feat else torch.empty(0, device=dev)
+    pos = torch.empty((B, L), dtype=torch.int32, device=dev)
+    logits = torch.empty((B, L, U), dtype=torch.float32, device=dev)
+    nb = lib().phonlp_pos_head_ws_bytes(B, L, E, H, U, TE)
+    ws = _ws(nb, dev)
+    check(lib().phonlp_pos_head_split(_p(enc), E, _p(sentlens), B, L, E, _p(Whid), _p(bhid), _p(Wclf), _p(bclf), _p(emb),
+                                      H, U, TE, _p(feat) if want_feat else None, _p(planes), _p(inv), _p(pos), _p(logits),
+                                      _p(ws), nb, _stream()), "phonlp_pos_head_split")
+    return planes, inv, pos, logits, feat

@@ -523,6 +523,32 @@ def test_label_rows4_pair_matches_row_major(dev, B, L, H, O):
                 assert abs(sc[r0[b, i]] - sc[rx[b, i]]) <= 1e-5 * sc.abs().max()
 
 
+@pytest.mark.parametrize("B,L,E,TE,H,U", [(7, 33, 64, 12, 24, 7), (16, 128, 768, 100, 400, 24)])
+def test_pos_head_split_image(dev, B, L, E, TE, H, U):
+    """pos_head_split = pos_head followed by split_rows(feat), bit for bit on the live rows (padded rows: zero planes),
+    with or without the fp32 feat output."""
+    from phonlp_amd import HeadWeights, ops
+    from phonlp_amd import synthetic as S
+    sd = S.make_state_dict(E, TE, H, U, 5, 5, seed=B)
+    w = HeadWeights.from_state_dict(sd, dev)
+    g = torch.Generator().manual_seed(L)
+    enc = torch.randn(B, L, E, generator=g).to(dev)
+    lens = torch.randint(1, L + 1, (B,), generator=g).to(torch.int32)
+    lens[0] = L
+    lens_d = lens.to(dev)
+    feat0, pos0, log0 = ops.pos_head(enc, lens_d, w.upos_hid_w, w.upos_hid_b, w.upos_clf_w, w.upos_clf_b, w.emb_dep)
+    p0, i0 = ops.split_rows(feat0.view(B * L, E + TE))
+    live = (torch.arange(L)[None, :] < lens[:, None]).reshape(-1)
+    for want_feat in (True, False):
+        p1, i1, pos1, log1, feat1 = ops.pos_head_split(enc, lens_d, w.upos_hid_w, w.upos_hid_b, w.upos_clf_w,
+                                                       w.upos_clf_b, w.emb_dep, want_feat)
+        assert torch.equal(pos1, pos0) and torch.equal(log1, log0)
+        assert torch.equal(p1.cpu()[live], p0.cpu()[live]) and torch.equal(i1.cpu()[live], i0.cpu()[live])
+        assert (p1.cpu()[~live] == 0).all()
+        if want_feat:
+            assert torch.equal(feat1, feat0)
+
+
 def test_streaming_batches_match_joined(dev):
     """annotate_batch(join=False) on back-to-back batches (tails on the finishing stream, next batch's GEMMs not
     waiting for the MST) gives exactly the outputs of the joined form."""
