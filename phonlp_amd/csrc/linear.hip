@@ -791,7 +791,17 @@ int launch_linear(const char *tag, const float *X, long ldx, const float *W, lon
     a.num_m = ceil_div(M, 128);
     const int eng = gemm_engine();
     if (N <= 64) {
+        // Narrow layers (upos_clf, ner_tag_clf) are HBM-bound row streams: 128-row blocks give one block per CU at
+        // B*L = 32768 (latency-bound); 32-row blocks of one wave give 4x the loads in flight (PHONLP_NARROW_BM=128: A/B).
         a.num_n = ceil_div(N, 32);
+        static const int narrow_bm = getenv("PHONLP_NARROW_BM") ? atoi(getenv("PHONLP_NARROW_BM")) : 32;
+        if (narrow_bm == 32 && M >= 4096) {
+            a.num_m = ceil_div(M, 32);
+            const dim3 g(a.num_m * a.num_n, nbatch);
+            if (eng) hipLaunchKernelGGL((linear_kernel<32, 32, 1, 1, 0, 1>), g, dim3(64), 0, stream, a);
+            else hipLaunchKernelGGL((linear_kernel<32, 32, 1, 1, 0, 0>), g, dim3(64), 0, stream, a);
+            return check_launch("linear_kernel");
+        }
         const dim3 g(persistent_grid(a.num_m * a.num_n), nbatch);
         if (eng) hipLaunchKernelGGL((linear_kernel<128, 32, 4, 1, 0, 1>), g, dim3(256), 0, stream, a);
         else hipLaunchKernelGGL((linear_kernel<128, 32, 4, 1, 0, 0>), g, dim3(256), 0, stream, a);

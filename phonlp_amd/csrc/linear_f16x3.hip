@@ -403,6 +403,45 @@ __global__ __launch_bounds__(256, 2) void linear_f16x3_dma_kernel(LinearArgs a) 
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+    // Fragments are double-buffered in registers: the ds_read_b128 of stage s+1 are issued BEFORE the MFMAs of stage
+    // s, so the matrix pipe never waits for an LDS read of its own stage.
+    struct Frags {
+        u32x4 ah[TM], al[TM], bh[TN], bl[TN];
+    };
+    auto read_frags = [&](int bufi, Frags &f) {
+        const unsigned char *buf = lds + bufi * BUF;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            f.bh[j] = *reinterpret_cast<const u32x4 *>(buf + b_ofs + j * 2048 + off_h);
+            f.bl[j] = *reinterpret_cast<const u32x4 *>(buf + b_ofs + j * 2048 + off_l);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            f.al[i] = *reinterpret_cast<const u32x4 *>(buf + a_ofs + i * 2048 + off_l);
+            f.ah[i] = *reinterpret_cast<const u32x4 *>(buf + a_ofs + i * 2048 + off_h);
+        }
+    };
+    auto mma_frags = [&](const Frags &f) {
+#define PHONLP_X3_ROUND(AA, BB)                      \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)   \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] = PHONLP_F16_MFMA(f.AA[i], f.BB[j], acc[i][j]);
+        PHONLP_X3_ROUND(al, bh)
+        PHONLP_X3_ROUND(ah, bl)
+        PHONLP_X3_ROUND(ah, bh)
+#undef PHONLP_X3_ROUND
+    };
+    // one stage: fetch stage s+2 into the buffer whose readers are all past the previous barrier, publish stage s+1
+    // (own pieces landed, then the barrier), prefetch its fragments, multiply stage s.
+    auto stage = [&](int s, const Frags &fc, Frags &fn) {
+        if (s + 2 < nst) issue_stage(s + 2, (s + 2) % NBUF);
+        if (s + 1 < nst) {
+            if (s + 2 < nst) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lds_barrier();
+            read_frags((s + 1) % NBUF, fn);
+        }
+        mma_frags(fc);
+    };
     issue_stage(0, 0);
     if (nst > 1) {
         issue_stage(1, 1);
@@ -411,36 +450,37 @@ __global__ __launch_bounds__(256, 2) void linear_f16x3_dma_kernel(LinearArgs a) 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
-    int cur = 0;
-    for (int s = 0; s < nst; ++s) {
-        const unsigned char *buf = lds + cur * BUF;
-        const int nxt2 = cur == 0 ? 2 : cur - 1;  // (cur + 2) % 3: last read in iteration s-1, behind that barrier
-        if (s + 2 < nst) issue_stage(s + 2, nxt2);
-        u32x4 ah[TM], al[TM], bh[TN], bl[TN];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            bh[j] = *reinterpret_cast<const u32x4 *>(buf + b_ofs + j * 2048 + off_h);
-            bl[j] = *reinterpret_cast<const u32x4 *>(buf + b_ofs + j * 2048 + off_l);
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            al[i] = *reinterpret_cast<const u32x4 *>(buf + a_ofs + i * 2048 + off_l);
-            ah[i] = *reinterpret_cast<const u32x4 *>(buf + a_ofs + i * 2048 + off_h);
-        }
-#define PHONLP_X3_ROUND(AA, BB)                      \
-    _Pragma("unroll") for (int i = 0; i < TM; ++i)   \
-    _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] = PHONLP_F16_MFMA(AA[i], BB[j], acc[i][j]);
-        PHONLP_X3_ROUND(al, bh)
-        PHONLP_X3_ROUND(ah, bl)
-        PHONLP_X3_ROUND(ah, bh)
-#undef PHONLP_X3_ROUND
-        // stage s+1 (issued one iteration ago) must have landed before anyone reads it; the 6 loads of stage s+2 issued
-        // above may stay in flight
-        if (s + 2 < nst) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    Frags f0, f1;
+    read_frags(0, f0);
+    // stage s+2 goes to buffer (s+2)%3, last read as stage s-1 by the prefetch of iteration s-2: every wave has been
+    // through the barrier of iteration s-1 since (lds_barrier waits for the wave's outstanding LDS reads first)
+    // The steady state is branch-free (a conditional around the prefetch makes hipcc wait for ALL LDS reads at the
+    // join, i.e. in front of the MFMAs); the last stages run through the guarded form.
+    auto stage_full = [&](int s, const Frags &fc, Frags &fn) {
+        issue_stage(s + 2, (s + 2) % NBUF);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         lds_barrier();
-        cur = cur == 2 ? 0 : cur + 1;
+        read_frags((s + 1) % NBUF, fn);
+        // MFMAs are register-only: unpinned, hipcc hoists them above the barrier, and the next stage's MFMAs then sit
+        // right behind their own reads.  An empty asm that "modifies" every accumulator pins them behind the reads
+        // (sched_barrier does too, but drives the register allocator into 500 spills here).
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(acc[i][j]));
+        mma_frags(fc);
+    };
+    int s = 0;
+    for (; s + 3 < nst; s += 2) {
+        stage_full(s, f0, f1);
+        stage_full(s + 1, f1, f0);
     }
+    for (; s < nst; s += 2) {
+        stage(s, f0, f1);
+        if (s + 1 < nst) stage(s + 1, f1, f0);
+    }
+    lds_barrier();  // the epilogue's LDS patch aliases the stage buffers
     if (a.dbg == 2) {  // timing only: keep the accumulators alive without the epilogue
         float t = 0.f;
 #pragma unroll
