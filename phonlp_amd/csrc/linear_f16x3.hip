@@ -18,6 +18,7 @@
 // 8 consecutive k is 32 bytes: h[8] then l[8].  A k16 stage of a row is therefore one 64-byte segment of four
 // 16-byte chunks (h0-7, l0-7, h8-15, l8-15), and an MFMA fragment (lane r, half hh: k = 8hh..8hh+7 of row r) is
 // chunk 2hh (h) / 2hh+1 (l).  inv_scale[row] = 1/s.
+#include <limits.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -188,24 +189,31 @@ __global__ void head_rows_kernel(const int32_t *heads, const int32_t *sentlens, 
 }
 
 // rels[m] = argmax_o sum_{t < gpo} P[o*gpo + t][m] (shares added in ascending t; strict '>' in ascending o), 0 for
-// words without a label.
-__global__ void label_reduce_kernel(const float *P, const int32_t *hrow, int M, int O, int gpo, int32_t *rels,
-                                    float *best_opt) {
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= M) return;
+// words without a label.  Block = 64 words x 8 relation classes (o mod 8), combined through LDS.
+__global__ __launch_bounds__(512) void label_reduce_kernel(const float *P, const int32_t *hrow, int M, int O, int gpo,
+                                                           int32_t *rels, float *best_opt) {
+    __shared__ float sv[8][64];
+    __shared__ int so[8][64];
+    const int lx = threadIdx.x & 63, oq = threadIdx.x >> 6;
+    const int m = blockIdx.x * 64 + lx;
+    const bool live = m < M && hrow[m] >= 0;
     float bv = -INFINITY;
-    int bo = 0;
-    if (hrow[m] >= 0) {
-        for (int o = 0; o < O; ++o) {
+    int bo = INT_MAX;
+    if (live)
+        for (int o = oq; o < O; o += 8) {
             float s = 0.f;
             for (int t = 0; t < gpo; ++t) s += P[(long)(o * gpo + t) * M + m];
             if (s > bv) { bv = s; bo = o; }
         }
-    } else {
-        bv = 0.f;
+    sv[oq][lx] = bv;
+    so[oq][lx] = bo;
+    __syncthreads();
+    if (oq == 0 && m < M) {
+        for (int q = 1; q < 8; ++q)
+            if (sv[q][lx] > bv || (sv[q][lx] == bv && so[q][lx] < bo)) { bv = sv[q][lx]; bo = so[q][lx]; }
+        rels[m] = live && bo != INT_MAX ? bo : 0;
+        if (best_opt) best_opt[m] = live && bo != INT_MAX ? bv : 0.f;
     }
-    rels[m] = bo;
-    if (best_opt) best_opt[m] = bv;
 }
 
 // 256 x 128 block tile, four waves of 128 x 64 (8 accumulator tiles), k16 stages, two 24 KB LDS buffers, one
@@ -624,6 +632,6 @@ extern "C" int phonlp_label_at_heads_fused(const void *X1p, const float *x1_inv,
                              O * KPC, K16, 0, nullptr, 0, st, nullptr, 0, &ah);
     if (rc) return rc;
     ProfScope ps("label_reduce", st);
-    hipLaunchKernelGGL(label_reduce_kernel, dim3(ceil_div(M, 256)), dim3(256), 0, st, P, hrow, M, O, KPC / 32, rels, best_opt);
+    hipLaunchKernelGGL(label_reduce_kernel, dim3(ceil_div(M, 64)), dim3(512), 0, st, P, hrow, M, O, KPC / 32, rels, best_opt);
     return check_launch("label_reduce_kernel");
 }

@@ -450,6 +450,40 @@ def test_headline_batch_properties(dev, engine):
     assert np.array_equal(big["rels"].cpu().numpy(), rel_want)
 
 
+def test_long_sentence_batch_properties(dev):
+    """BASELINE config 5 (B=64, L=512): the whole path at four times the headline length (block-synchronous MST with
+    the float64 matrix in the workspace, multi-tile label stage B, engine-2 split images).  Sub-batch == big batch bit
+    for bit; heads == the C oracle's on the GPU's arc scores (sample of sentences); relations == the dense label
+    scorer's arg-max at those heads except at provable near-ties."""
+    from phonlp_amd import HeadWeights, TaskHeads, ops
+    from phonlp_amd import synthetic as S
+    B, L = 64, 512
+    sd = S.make_state_dict()
+    enc_dep, enc_tag = S.make_encoder_outputs(B, L)
+    lens1 = S.make_sentlens(B, L, True)
+    lens1[0] = L
+    lens = [n - 1 for n in lens1]
+    heads = TaskHeads(HeadWeights.from_state_dict(sd, dev))
+    big = heads.annotate_batch(enc_dep.to(dev), lens1, enc_tag.to(dev), lens)
+    assert (big["mst_status"] == 0).all()
+    sub = slice(10, 18)
+    small = heads.annotate_batch(enc_dep[sub].to(dev), lens1[sub], enc_tag[sub].to(dev), lens[sub])
+    for k in ("pos", "ner", "heads", "rels"):
+        assert torch.equal(big[k][sub], small[k]), k
+    pick = [0, 1, 7, 20, 33, 63]
+    dep = heads.parser(enc_dep[pick].to(dev), [lens1[i] for i in pick], want_label_scores=True)
+    h = big["heads"].cpu().numpy()[pick]
+    wh, ws = C.mst_batch(dep["arc_logp"].cpu().numpy(), [lens1[i] for i in pick])
+    assert not ws.any() and np.array_equal(h, wh)
+    rels = big["rels"].cpu()[pick]
+    scores = dep["label_scores"].cpu()  # [b, i, o, j]
+    for bi, b in enumerate(pick):
+        for i in range(1, lens1[b]):
+            sc = scores[bi, i, :, h[bi, i]]
+            assert sc[rels[bi, i]] >= sc.max() - 1e-4 * max(1.0, float(sc.abs().max())), (b, i)
+        assert (rels[bi, lens1[b]:] == 0).all() and rels[bi, 0] == 0
+
+
 # ------------------------------------------------------------------------------------------ glue kernels (section 8f)
 @pytest.mark.parametrize("B,L,H,O", [(6, 37, 24, 5), (16, 128, 400, 33)])
 def test_label_at_heads_matches_dense_label_scorer(dev, engine, B, L, H, O):
