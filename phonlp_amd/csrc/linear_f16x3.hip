@@ -511,6 +511,128 @@ __global__ __launch_bounds__(256, 2) void linear_f16x3_dma_kernel(LinearArgs a) 
     linear_epilogue<TM, TN, WM, WN>(acc, reinterpret_cast<float *>(lds), a, m0, n0, wm, wn, lane, wave);
 }
 
+// The same kernel with the fragments read at the top of their own stage (no register prefetch, 196 VGPRs): used for
+// short K (launch_linear_f16x3).
+template <int TAG>
+__global__ __launch_bounds__(256, 2) void linear_f16x3_dma_np_kernel(LinearArgs a) {
+    constexpr int BM = 256, BN = 128, WM = 2, WN = 2, TM = 4, TN = 2, NBUF = 3;
+    constexpr int ROWS = BM + BN, BUF = ROWS * 64;
+    static_assert(WM * WN * 32 * (TN * 32 + 4) * 4 <= NBUF * BUF, "epilogue patch must fit");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int ntiles = a.num_m * a.num_n;
+    const int nst = a.K >> 4;
+    int m0, n0;
+    {
+        const int xg = blockIdx.x & 7, jl = blockIdx.x >> 3;
+        const int q = ntiles >> 3, r = ntiles & 7;
+        const int t = (xg < r ? xg * (q + 1) : r * (q + 1) + (xg - r) * q) + jl;
+        constexpr int GM = 4;
+        const int per_group = GM * a.num_n;
+        const int g = t / per_group;
+        const int first_m = g * GM;
+        const int gsz = (a.num_m - first_m) < GM ? (a.num_m - first_m) : GM;
+        const int in = t - g * per_group;
+        m0 = (first_m + in % gsz) * BM;
+        n0 = (in / gsz) * BN;
+    }
+    // wave-load u = 4q + wave (q = 0..5) fills rows 16u .. 16u+15 of the stage image (A rows 0-255, B rows 256-383)
+    const int lr = lane >> 2, chunk = (lane & 3) ^ ((lane >> 4) & 3);
+    const unsigned char *src[6];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int row = m0 + 16 * (4 * q + wave) + lr;
+        row = row < a.M ? row : a.M - 1;
+        src[q] = reinterpret_cast<const unsigned char *>(a.X) + (long)row * a.ldx + chunk * 16;
+    }
+#pragma unroll
+    for (int q = 4; q < 6; ++q) {
+        int row = n0 + 16 * (4 * (q - 4) + wave) + lr;
+        row = row < a.N ? row : a.N - 1;
+        src[q] = reinterpret_cast<const unsigned char *>(a.W) + (long)row * a.ldw + chunk * 16;
+    }
+    const unsigned lds0 = (unsigned)(uintptr_t)lds + (unsigned)__builtin_amdgcn_readfirstlane(wave) * 1024u;
+    auto issue_stage = [&](int st, int buf) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) lds_dma16(src[q] + (long)st * 64, lds0 + (unsigned)(buf * BUF + q * 4096));
+    };
+
+    const int r = lane & 31, hh = lane >> 5;
+    const int sw = (r >> 2) & 3;
+    const int off_h = ((2 * hh) ^ sw) << 4, off_l = ((2 * hh + 1) ^ sw) << 4;
+    const int a_ofs = (wm * 128 + r) * 64;
+    const int b_ofs = (BM + wn * 64 + r) * 64;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    issue_stage(0, 0);
+    if (nst > 1) {
+        issue_stage(1, 1);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    int cur = 0;
+    for (int s = 0; s < nst; ++s) {
+        const unsigned char *buf = lds + cur * BUF;
+        const int nxt2 = cur == 0 ? 2 : cur - 1;  // (cur + 2) % 3: last read in iteration s-1, behind that barrier
+        if (s + 2 < nst) issue_stage(s + 2, nxt2);
+        u32x4 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            bh[j] = *reinterpret_cast<const u32x4 *>(buf + b_ofs + j * 2048 + off_h);
+            bl[j] = *reinterpret_cast<const u32x4 *>(buf + b_ofs + j * 2048 + off_l);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            al[i] = *reinterpret_cast<const u32x4 *>(buf + a_ofs + i * 2048 + off_l);
+            ah[i] = *reinterpret_cast<const u32x4 *>(buf + a_ofs + i * 2048 + off_h);
+        }
+#define PHONLP_X3_ROUND(AA, BB)                      \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)   \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] = PHONLP_F16_MFMA(AA[i], BB[j], acc[i][j]);
+        PHONLP_X3_ROUND(al, bh)
+        PHONLP_X3_ROUND(ah, bl)
+        PHONLP_X3_ROUND(ah, bh)
+#undef PHONLP_X3_ROUND
+        // stage s+1 (issued one iteration ago) must have landed before anyone reads it; the 6 loads of stage s+2 issued
+        // above may stay in flight
+        if (s + 2 < nst) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();
+        cur = cur == 2 ? 0 : cur + 1;
+    }
+    if (a.dbg == 2) {  // timing only: keep the accumulators alive without the epilogue
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) t += acc[i][j][e];
+        if (t == 1234.5f) a.Y[tid] = t;
+        return;
+    }
+    if (a.rows4 == 2) {
+        at_heads_epilogue<TM, TN>(acc, a, m0, n0, wm, wn, lane);
+        return;
+    }
+    if (a.rows4) {
+        rows4_epilogue<TM, TN>(acc, a, m0, n0, wm, wn, lane);
+        return;
+    }
+    linear_epilogue<TM, TN, WM, WN>(acc, reinterpret_cast<float *>(lds), a, m0, n0, wm, wn, lane, wave);
+}
+
 int launch_linear_f16x3(const char *tag, const void *Xp, long pitch_x, const float *x_inv, const void *Wp, long pitch_w,
                         const float *w_inv, const float *bias, float *Y, long ldy, int M, int N, int K16, int relu,
                         const int32_t *sentlens, int L, hipStream_t stream, const float *pad_bias, int rows4 = 0,
@@ -552,6 +674,21 @@ int launch_linear_f16x3(const char *tag, const void *Xp, long pitch_x, const flo
         if (stage_a) hipLaunchKernelGGL((linear_f16x3_kernel<1>), g, dim3(256), LDS, stream, a);
         else hipLaunchKernelGGL((linear_f16x3_kernel<0>), g, dim3(256), LDS, stream, a);
         return check_launch("linear_f16x3_kernel");
+    }
+    // measured (tools/f16x3_probe.py, one box): the register-prefetch loop wins on long K (W1/W2, K = 868: 0.456 vs
+    // 0.482 ms) and loses on short K (stage A, K = 408: 1.65 vs 1.55 ms, its 256 VGPRs cost the epilogue); K16 picks.
+    static const int pf_env = getenv("PHONLP_X3_PREFETCH") ? atoi(getenv("PHONLP_X3_PREFETCH")) : -1;
+    const bool prefetch = pf_env >= 0 ? pf_env != 0 : K16 >= 512;
+    if (!prefetch) {
+        static bool np_attr = false;
+        if (!np_attr) {
+            (void)hipFuncSetAttribute((const void *)linear_f16x3_dma_np_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DMA);
+            (void)hipFuncSetAttribute((const void *)linear_f16x3_dma_np_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DMA);
+            np_attr = true;
+        }
+        if (stage_a) hipLaunchKernelGGL((linear_f16x3_dma_np_kernel<1>), g, dim3(256), LDS_DMA, stream, a);
+        else hipLaunchKernelGGL((linear_f16x3_dma_np_kernel<0>), g, dim3(256), LDS_DMA, stream, a);
+        return check_launch("linear_f16x3_dma_np_kernel");
     }
     if (stage_a) hipLaunchKernelGGL((linear_f16x3_dma_kernel<1>), g, dim3(256), LDS_DMA, stream, a);
     else hipLaunchKernelGGL((linear_f16x3_dma_kernel<0>), g, dim3(256), LDS_DMA, stream, a);
