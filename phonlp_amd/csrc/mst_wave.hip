@@ -26,6 +26,8 @@
 // waits for late pushes, and then only while every workgroup of the grid has started (all of them are then resident
 // and finish their first decode without needing its CU); if some have not started yet it exits, so the grid always
 // drains.
+#include <type_traits>
+
 #include "mst.h"
 
 namespace phonlp {
@@ -85,13 +87,50 @@ static WaveLayout wave_layout(int L) {
 }
 bool mst_wave_fits(int L) { return L <= 255 && wave_layout(L).stack_cap >= 4 * L; }
 
+// Cross-lane exchanges inside a 16-lane row as DPP moves (quad_perm / row_half_mirror / row_mirror: VALU operand
+// modifiers, a few cycles) instead of ds_bpermute round trips through the LDS crossbar (~100 cycles each, and the
+// level loop is one long dependent chain).  The four patterns pair lane groups of 1, 2, 4 and 8, so applying them in
+// turn leaves every lane of the row with the row's reduction; max / arg-max with the lowest-index tie-break are
+// order-independent, so the results are those of the xor butterfly.
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = dpp_i<CTRL>((int)(b & 0xFFFFFFFFll)), hi = dpp_i<CTRL>((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140;
+
 __device__ __forceinline__ int wave_max_i(int v) {
+    int t;
+    t = dpp_i<DPP_XOR1>(v); v = t > v ? t : v;
+    t = dpp_i<DPP_XOR2>(v); v = t > v ? t : v;
+    t = dpp_i<DPP_HALF_MIRROR>(v); v = t > v ? t : v;
+    t = dpp_i<DPP_MIRROR>(v); v = t > v ? t : v;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const int t = __shfl_xor(v, o);
+    for (int o = 16; o <= 32; o <<= 1) {
+        t = __shfl_xor(v, o);
         v = t > v ? t : v;
     }
     return v;
+}
+
+// (value, index) arg-max across the 16 lanes of a row: greatest value, lowest index among equals
+template <int CTRL>
+__device__ __forceinline__ void argmax_step(double &bv, int &bi) {
+    const double v2 = dpp_d<CTRL>(bv);
+    const int i2 = dpp_i<CTRL>(bi);
+    if (v2 > bv || (v2 == bv && i2 < bi)) { bv = v2; bi = i2; }
+}
+__device__ __forceinline__ int row16_argmax(double bv, int bi) {
+    argmax_step<DPP_XOR1>(bv, bi);
+    argmax_step<DPP_XOR2>(bv, bi);
+    argmax_step<DPP_HALF_MIRROR>(bv, bi);
+    argmax_step<DPP_MIRROR>(bv, bi);
+    return bi;
 }
 
 // first-maximum arg-max of logical row `row` over logical columns [0, n), by the 16 lanes of a group
@@ -104,13 +143,7 @@ __device__ __forceinline__ int row_argmax16(const double *S, int pitch, const in
         const double v = S[(long)rs * pitch + node[c]];
         if (v > bv) { bv = v; bi = c; }
     }
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) {
-        const double v2 = __shfl_xor(bv, o, 16);
-        const int i2 = __shfl_xor(bi, o, 16);
-        if (v2 > bv || (v2 == bv && i2 < bi)) { bv = v2; bi = i2; }
-    }
-    return bi;
+    return row16_argmax(bv, bi);
 }
 
 // The same arg-max with the lane's column slots (node[sub + 16 t]) already in registers: all of the row's loads
@@ -127,13 +160,7 @@ __device__ __forceinline__ int row_argmax16_cols(const double *S, int pitch, int
 #pragma unroll
     for (int t = 1; t < NC; ++t)
         if (sub + 16 * t < n && vals[t] > bv) { bv = vals[t]; bi = sub + 16 * t; }
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) {
-        const double v2 = __shfl_xor(bv, o, 16);
-        const int i2 = __shfl_xor(bi, o, 16);
-        if (v2 > bv || (v2 == bv && i2 < bi)) { bv = v2; bi = i2; }
-    }
-    return bi;
+    return row16_argmax(bv, bi);
 }
 
 template <int NPL>
@@ -288,7 +315,12 @@ __global__ __launch_bounds__(256) void mst_wave_kernel(MstArgs a, int stack_cap)
                 for (int x = lane; x < c; x += 64) { REC_ST(x, cyc[x]); REC_ST(c + x, hdA[cyc[x]]); }
                 // best way into the cycle from every outside node / best head inside it (ref :84-99)
                 const int ms = node[cyc[0]];
-                constexpr int CU = 4;  // members handled with all loads in flight (cycles of 2-3 nodes dominate)
+                int my_slot[NPL], my_newhead[NPL], my_need[NPL];
+                double my_ev[NPL], my_lv[NPL];
+                // CU = members handled with all loads in flight; cycles of 2 nodes dominate, then 3: two instantiations
+                // so that a 2-cycle does not pay for four members' loads
+                auto enter_leave = [&](auto CUc) __attribute__((always_inline)) {
+                constexpr int CU = decltype(CUc)::value;
                 int csm[CU];
                 double em[CU];
 #pragma unroll
@@ -296,8 +328,6 @@ __global__ __launch_bounds__(256) void mst_wave_kernel(MstArgs a, int stack_cap)
                     csm[m] = m < c ? node[cyc[m]] : ms;
                     em[m] = m < c ? edge[m] : 0.0;
                 }
-                int my_slot[NPL], my_newhead[NPL], my_need[NPL];
-                double my_ev[NPL], my_lv[NPL];
 #pragma unroll
                 for (int q = 0; q < NPL; ++q) {
                     const int x = lane + 64 * q;
@@ -336,6 +366,9 @@ __global__ __launch_bounds__(256) void mst_wave_kernel(MstArgs a, int stack_cap)
                         if (incyc[h]) my_need[q] = 1; else my_newhead[q] = rankr[h];
                     }
                 }
+                };
+                if (c <= 2) enter_leave(std::integral_constant<int, 2>{});
+                else enter_leave(std::integral_constant<int, 4>{});
                 WFENCE();
                 STAMP(5);
                 // contract in place; rows that pointed into the cycle (and the metanode) go on the rescan list
