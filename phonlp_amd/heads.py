@@ -218,12 +218,20 @@ class TaskHeads:
         start = torch.cuda.Event()
         start.record(main)
         # tagger chain on its own stream
-        s_tag.wait_event(start)
-        with torch.cuda.stream(s_tag):
-            tag = self.tagger(enc_tag, lens_t)
-            ner, _ = ops.crf_viterbi(tag["ner_logits"], w.trans, lens_t)
-            tag_done = torch.cuda.Event()
-            tag_done.record(s_tag)
+        def run_tagger(after):
+            s_tag.wait_event(after)
+            with torch.cuda.stream(s_tag):
+                tag = self.tagger(enc_tag, lens_t)
+                ner, _ = ops.crf_viterbi(tag["ner_logits"], w.trans, lens_t)
+                tag_done = torch.cuda.Event()
+                tag_done.record(s_tag)
+            return tag, ner, tag_done
+
+        # PHONLP_TAGGER_LATE=1 (A/B): start the tagger chain when the arc scores are done, beside the MST and stage A,
+        # instead of beside the parser's own POS head and arc GEMMs
+        tagger_late = os.environ.get("PHONLP_TAGGER_LATE", "0") == "1"
+        if not tagger_late:
+            tag, ner, tag_done = run_tagger(start)
         # parser chain up to the arc log-probs on the main stream
         B, Ld, D = enc_dep.shape[0], enc_dep.shape[1], enc_dep.shape[2] + w.emb_dep.shape[1]
         split = ops.get_gemm_engine() == 2 and w.lab_Wbt_s is not None
@@ -242,6 +250,8 @@ class TaskHeads:
                                                 w.linearization, w.distance, False, lens_d, w.arc_b12)
         arc_done = torch.cuda.Event()
         arc_done.record(main)
+        if tagger_late:
+            tag, ner, tag_done = run_tagger(arc_done)
         # MST beside the label scorer
         s_mst.wait_event(arc_done)
         arc_logp.record_stream(s_mst)
