@@ -1,6 +1,7 @@
 // POS head tail (softmax / arg-max / soft POS embedding), NER emissions, dep_hid, and the error plumbing.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -59,16 +60,30 @@ int launch_linear(const char *tag, const float *X, long ldx, const float *W, lon
                   int N, int K, int relu, const int32_t *sentlens, int L, hipStream_t stream, const float *pad_bias = nullptr, int nbatch = 1,
                   long bsx = 0, long bsw = 0, long bsy = 0);
 
+// engine 2 (linear_f16x3.hip)
+struct LinearArgs;
+int gemm_engine();
+int launch_split_rows(const float *X, long ldx, int rows, int K, void *planes, long pitch, float *inv_scale, hipStream_t stream);
+int launch_linear_f16x3(const char *tag, const void *Xp, long pitch_x, const float *x_inv, const void *Wp, long pitch_w,
+                        const float *w_inv, const float *bias, float *Y, long ldy, int M, int N, int K16, int relu,
+                        const int32_t *sentlens, int L, hipStream_t stream, const float *pad_bias, int rows4 = 0,
+                        const LinearArgs *at_heads = nullptr);
+
 // One wavefront per token.  logits [M, U] (U <= 64) -> pos_pred, feat = [enc | softmax(logits) . emb].
 // ref annotate_model.py:138-146 / :177-183.  The row is assembled in this wave's LDS buffer; from there it goes out as
 // the fp32 feat row (feat != NULL) and / or as its engine-2 split image (planes != NULL: the arithmetic of
 // split_rows_kernel, linear_f16x3.hip, so the large layers that follow need no split pass over feat).
+// `presplit` (with planes, E % 8 == 0): the enc columns of the image and inv_scale[tok] are already in place, written
+// by split_rows_kernel from the enc row alone (pos_head_impl does that to feed upos_hid's engine-2 GEMM).  The row's
+// scale depends only on the exponent of its largest magnitude, so as long as the soft POS embedding does not exceed
+// the enc part's exponent the image of [enc | emb] keeps that scale and only the emb columns are written here; a row
+// whose embedding is larger is redone whole.  Either way the image equals split_rows_kernel's of the feat row.
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 
 __global__ __launch_bounds__(256) void pos_tail_kernel(const float *enc, long ld_enc, const float *logits,
                                                        const float *emb, const int32_t *sentlens, int M, int L, int E,
                                                        int U, int TE, float *feat, int32_t *pos_pred,
-                                                       unsigned char *planes, float *inv_scale) {
+                                                       unsigned char *planes, float *inv_scale, int presplit) {
     extern __shared__ __attribute__((aligned(16))) float rows[];
     const int lane = threadIdx.x & 63;
     const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -111,24 +126,38 @@ __global__ __launch_bounds__(256) void pos_tail_kernel(const float *enc, long ld
         mx = max(mx, __float_as_uint(acc) & 0x7FFFFFFFu);
     }
     for (int c = D + lane; c < K16; c += 64) row[c] = 0.f;
-    const float *erow = enc + (long)tok * ld_enc;
-    for (int c = lane * 4; c < E; c += 256) {
-        const float4 v = *reinterpret_cast<const float4 *>(erow + c);
-        *reinterpret_cast<float4 *>(row + c) = v;
-        mx = max(max(mx, __float_as_uint(v.x) & 0x7FFFFFFFu), max(__float_as_uint(v.y) & 0x7FFFFFFFu,
-                 max(__float_as_uint(v.z) & 0x7FFFFFFFu, __float_as_uint(v.w) & 0x7FFFFFFFu)));
+    bool fast = prow && presplit;  // wave-uniform
+    int Ex = 0;
+    if (fast) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
+        int Ee = (int)(mx >> 23);
+        Ee = Ee < 16 ? 16 : (Ee > 254 ? 254 : Ee);
+        Ex = (int)(__float_as_uint(inv_scale[tok]) >> 23) + 14;  // the enc part's exponent (split_rows_kernel)
+        if (Ee > Ex) fast = false;
+    }
+    if (frow || !fast) {
+        const float *erow = enc + (long)tok * ld_enc;
+        for (int c = lane * 4; c < E; c += 256) {
+            const float4 v = *reinterpret_cast<const float4 *>(erow + c);
+            *reinterpret_cast<float4 *>(row + c) = v;
+            mx = max(max(mx, __float_as_uint(v.x) & 0x7FFFFFFFu), max(__float_as_uint(v.y) & 0x7FFFFFFFu,
+                     max(__float_as_uint(v.z) & 0x7FFFFFFFu, __float_as_uint(v.w) & 0x7FFFFFFFu)));
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (frow)
         for (int c = lane * 4; c < D; c += 256) *reinterpret_cast<float4 *>(frow + c) = *reinterpret_cast<const float4 *>(row + c);
     if (prow) {
+        if (!fast) {
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
-        int Ex = (int)(mx >> 23);
-        Ex = Ex < 16 ? 16 : (Ex > 254 ? 254 : Ex);
+            for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
+            Ex = (int)(mx >> 23);
+            Ex = Ex < 16 ? 16 : (Ex > 254 ? 254 : Ex);
+            if (lane == 0) inv_scale[tok] = __uint_as_float((unsigned)(Ex - 14) << 23);
+        }
         const float scale = __uint_as_float((unsigned)(268 - Ex) << 23);
-        if (lane == 0) inv_scale[tok] = __uint_as_float((unsigned)(Ex - 14) << 23);
-        for (int g = lane; g * 8 < K16; g += 64) {
+        for (int g = (fast ? E / 8 : 0) + lane; g * 8 < K16; g += 64) {
             h16x8 h, l;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -187,9 +216,12 @@ extern "C" const char *phonlp_profile_tag_name(int id) {
 extern "C" const char *phonlp_last_error(void) { return g_err; }
 
 extern "C" size_t phonlp_pos_head_ws_bytes(int B, int L, int E, int H, int U, int TE) {
-    (void)E; (void)TE;
+    (void)TE;
     const size_t M = (size_t)B * L;
-    return align_up(M * H * sizeof(float), 256) + align_up(M * U * sizeof(float), 256);
+    // hid, logits; then (engine 2) the split images of enc and Whid that feed upos_hid's GEMM
+    return align_up(M * H * sizeof(float), 256) + align_up(M * U * sizeof(float), 256) +
+           align_up(phonlp_split_bytes((int)M, E), 256) + align_up(M * sizeof(float), 256) +
+           align_up(phonlp_split_bytes(H, E), 256) + align_up((size_t)H * sizeof(float), 256);
 }
 
 static int pos_head_impl(const float *enc, int ld_enc, const int32_t *sentlens, int B, int L, int E, const float *Whid,
@@ -209,7 +241,34 @@ static int pos_head_impl(const float *enc, int ld_enc, const int32_t *sentlens, 
     const int M = B * L;
     float *hid = (float *)ws;
     float *logits = upos_logits ? upos_logits : (float *)((char *)ws + align_up((size_t)M * H * sizeof(float), 256));
-    int rc = launch_linear("linear:upos_hid", enc, ld_enc, Whid, E, bhid, hid, H, M, H, E, 1, sentlens, L, st);
+    // Engine 2: upos_hid on split images.  enc is split once -- straight into the enc columns of the feat image when
+    // the caller wants one (pos_tail_kernel then only adds the embedding columns), else into the workspace; Whid (H
+    // rows) is split per call.  E % 8 == 0 keeps the enc columns on whole 32-byte groups of the image.
+    static const bool x3_off = getenv("PHONLP_POS_X3") && atoi(getenv("PHONLP_POS_X3")) == 0;  // A/B switch
+    const bool x3 = gemm_engine() == 2 && (E % 8) == 0 && !x3_off;
+    int rc;
+    int presplit = 0;
+    if (x3) {
+        char *p = (char *)ws + align_up((size_t)M * H * sizeof(float), 256) + align_up((size_t)M * U * sizeof(float), 256);
+        void *encp = p;             p += align_up(phonlp_split_bytes(M, E), 256);
+        float *enci = (float *)p;   p += align_up((size_t)M * sizeof(float), 256);
+        void *whp = p;              p += align_up(phonlp_split_bytes(H, E), 256);
+        float *whi = (float *)p;
+        const int K16e = (E + 15) / 16 * 16;
+        long pitch = 4L * K16e;
+        if (feat_planes) {
+            encp = feat_planes; enci = feat_inv_scale; pitch = 4L * ((E + TE + 15) / 16 * 16);
+            presplit = 1;
+        }
+        rc = launch_split_rows(enc, ld_enc, M, E, encp, pitch, enci, st);
+        if (rc) return rc;
+        rc = launch_split_rows(Whid, E, H, E, whp, 0, whi, st);
+        if (rc) return rc;
+        rc = launch_linear_f16x3("linear:upos_hid", encp, pitch, enci, whp, 4L * K16e, whi, bhid, hid, H, M, H, K16e, 1,
+                                 sentlens, L, st, nullptr);
+    } else {
+        rc = launch_linear("linear:upos_hid", enc, ld_enc, Whid, E, bhid, hid, H, M, H, E, 1, sentlens, L, st);
+    }
     if (rc) return rc;
     rc = launch_linear("linear:upos_clf", hid, H, Wclf, H, bclf, logits, U, M, U, H, 0, sentlens, L, st);
     if (rc) return rc;
@@ -217,7 +276,7 @@ static int pos_head_impl(const float *enc, int ld_enc, const int32_t *sentlens, 
     if (lds > 64 * 1024) return fail(PHONLP_ERR_UNSUPPORTED, "pos_head: E + TE too large for the row buffers");
     ProfScope ps("pos_tail", st);
     hipLaunchKernelGGL(pos_tail_kernel, dim3(ceil_div(M, 4)), dim3(256), lds, st, enc, (long)ld_enc, logits, emb, sentlens,
-                       M, L, E, U, TE, feat, pos_pred, (unsigned char *)feat_planes, feat_inv_scale);
+                       M, L, E, U, TE, feat, pos_pred, (unsigned char *)feat_planes, feat_inv_scale, presplit);
     return check_launch("pos_tail_kernel");
 }
 

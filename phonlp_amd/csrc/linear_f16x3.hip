@@ -33,8 +33,9 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // ------------------------------------------------------------------------------------------ split
 // One wavefront per row.  K % 4 == 0, X 16-byte aligned, ldx % 4 == 0.
+// `pitch` = bytes between image rows (>= 4*K16: the image may be the leading columns of a wider one).
 __global__ __launch_bounds__(256) void split_rows_kernel(const float *X, long ldx, int rows, int K, int K16,
-                                                          unsigned char *planes, float *inv_scale) {
+                                                          unsigned char *planes, long pitch, float *inv_scale) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -53,7 +54,7 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float *X, long ld
     E = E < 16 ? 16 : (E > 254 ? 254 : E);
     const float scale = __uint_as_float((unsigned)(268 - E) << 23);  // 2^(14 - (E - 127)): maximum -> [2^14, 2^15)
     if (lane == 0) inv_scale[row] = __uint_as_float((unsigned)(E - 14) << 23);
-    unsigned char *out = planes + (long)row * K16 * 4;
+    unsigned char *out = planes + (long)row * pitch;
     for (int g = lane; g * 8 < K16; g += 64) {
         float v[8];
 #pragma unroll
@@ -704,15 +705,24 @@ extern "C" size_t phonlp_split_bytes(int rows, int K) {
     return (size_t)rows * (size_t)((K + 15) / 16 * 16) * 4;
 }
 
-extern "C" int phonlp_split_rows(const float *X, int ldx, int rows, int K, void *planes, float *inv_scale, void *stream) {
+namespace phonlp {
+// Split image of X [rows, K] written with row pitch `pitch` bytes (0 = packed, 4*K16).
+int launch_split_rows(const float *X, long ldx, int rows, int K, void *planes, long pitch, float *inv_scale,
+                      hipStream_t stream) {
     if (!X || !planes || !inv_scale || rows <= 0 || K <= 0) return fail(PHONLP_ERR_SHAPE, "split_rows: bad argument");
-    if ((K & 3) || (ldx & 3) || ((uintptr_t)X & 15) || ((uintptr_t)planes & 15))
-        return fail(PHONLP_ERR_SHAPE, "split_rows: K, ldx must be multiples of 4 and X, planes 16-byte aligned");
     const int K16 = (K + 15) / 16 * 16;
-    ProfScope ps("split_rows", as_stream(stream));
-    hipLaunchKernelGGL(split_rows_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, as_stream(stream), X, (long)ldx, rows, K,
-                       K16, reinterpret_cast<unsigned char *>(planes), inv_scale);
+    if (pitch == 0) pitch = 4L * K16;
+    if ((K & 3) || (ldx & 3) || ((uintptr_t)X & 15) || ((uintptr_t)planes & 15) || (pitch & 15) || pitch < 4L * K16)
+        return fail(PHONLP_ERR_SHAPE, "split_rows: K, ldx must be multiples of 4 and X, planes 16-byte aligned");
+    ProfScope ps("split_rows", stream);
+    hipLaunchKernelGGL(split_rows_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, stream, X, ldx, rows, K, K16,
+                       reinterpret_cast<unsigned char *>(planes), pitch, inv_scale);
     return check_launch("split_rows_kernel");
+}
+}  // namespace phonlp
+
+extern "C" int phonlp_split_rows(const float *X, int ldx, int rows, int K, void *planes, float *inv_scale, void *stream) {
+    return launch_split_rows(X, ldx, rows, K, planes, 0, inv_scale, as_stream(stream));
 }
 
 extern "C" int phonlp_linear_split(const void *Xp, const float *x_inv, const void *Wp, const float *w_inv,

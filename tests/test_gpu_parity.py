@@ -557,13 +557,18 @@ def test_label_rows4_pair_matches_row_major(dev, B, L, H, O):
                 assert abs(sc[r0[b, i]] - sc[rx[b, i]]) <= 1e-5 * sc.abs().max()
 
 
-@pytest.mark.parametrize("B,L,E,TE,H,U", [(7, 33, 64, 12, 24, 7), (16, 128, 768, 100, 400, 24)])
-def test_pos_head_split_image(dev, B, L, E, TE, H, U):
+@pytest.mark.parametrize("B,L,E,TE,H,U,emb_scale", [(7, 33, 64, 12, 24, 7, 1.0), (7, 33, 64, 12, 24, 7, 4.0),
+                                                     (9, 21, 64, 12, 24, 7, 50.0), (5, 19, 24, 8, 16, 7, 1.0),
+                                                     (16, 128, 768, 100, 400, 24, 1.0)])
+def test_pos_head_split_image(dev, B, L, E, TE, H, U, emb_scale):
     """pos_head_split = pos_head followed by split_rows(feat), bit for bit on the live rows (padded rows: zero planes),
-    with or without the fp32 feat output."""
+    with or without the fp32 feat output.  Under engine 2 the enc columns of the image are written before the
+    embedding exists; emb_scale > 1 makes the embedding exceed the enc part's exponent on some / all rows, which
+    takes the kernel's redo-the-row path."""
     from phonlp_amd import HeadWeights, ops
     from phonlp_amd import synthetic as S
     sd = S.make_state_dict(E, TE, H, U, 5, 5, seed=B)
+    sd["upos_emb_matrix_dep"] = sd["upos_emb_matrix_dep"] * emb_scale
     w = HeadWeights.from_state_dict(sd, dev)
     g = torch.Generator().manual_seed(L)
     enc = torch.randn(B, L, E, generator=g).to(dev)
