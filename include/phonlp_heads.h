@@ -54,7 +54,7 @@ const char *phonlp_last_error(void);
  * rows are written as exact zeros (pad_packed_sequence semantics, annotate_model.py:150,187).
  * Requires K % 4 == 0, ldx % 4 == 0, ldw % 4 == 0, 16-byte aligned X and W.
  */
-/* GEMM engine used by every matrix kernel of the library (process-wide; default 1, or $PHONLP_GEMM_ENGINE):
+/* GEMM engine used by every matrix kernel of the library (process-wide; default 2, or $PHONLP_GEMM_ENGINE):
  *   0  v_mfma_f32_32x32x2_f32: exact fp32 multiply-add chain;
  *   1  "bf16x6": each fp32 operand split exactly into three bf16 pieces in registers, six
  *      v_mfma_f32_32x32x16_bf16 products, fp32 accumulate -- fp32-equivalent (dropped terms <= 3*2^-24 |a||b|),
@@ -277,8 +277,11 @@ int phonlp_ner_entity_counts(const int32_t *pred, const int32_t *gold, const int
  * on its launch stream (up to max_samples launches).  _end synchronises those events and copies the
  * durations (milliseconds) and a tag id per launch to HOST arrays; returns the number of samples or a
  * negative error.  phonlp_profile_tag_name(id) names a tag ("linear:label_stage_a", "mst", ...).
+ * phonlp_profile_only(tag) restricts the sampling to launches with that tag (NULL or "" = every launch): an event
+ * pair costs a few microseconds of queue time per launch, so a timed run brackets only the kernel it reports.
  */
 int phonlp_profile_begin(int max_samples);
+int phonlp_profile_only(const char *tag);
 int phonlp_profile_end(float *ms_out_host, int32_t *tag_out_host, int cap);
 const char *phonlp_profile_tag_name(int id);
 

@@ -50,6 +50,7 @@ SIGNATURES = {
     "phonlp_eval_counts": (_i, [_p] * 11 + [_i, _i, _i, _p, _p]),
     "phonlp_profile_begin": (_i, [_i]),
     "phonlp_profile_end": (_i, [_p, _p, _i]),
+    "phonlp_profile_only": (_i, [ctypes.c_char_p]),
     "phonlp_profile_tag_name": (ctypes.c_char_p, [_i]),
 }
 

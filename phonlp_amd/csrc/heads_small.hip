@@ -37,6 +37,7 @@ struct ProfState {
     std::vector<hipEvent_t> ev;      // 2 per sample
     std::vector<int> tag;            // tag id per sample
     std::vector<std::string> names;  // tag registry
+    std::string only;                // non-empty: sample launches with this tag only
 } g_prof;
 }  // namespace
 
@@ -44,6 +45,7 @@ ProfScope::ProfScope(const char *tag, hipStream_t s) : slot(-1), stream(s) {
     if (!g_prof.on) return;
     std::lock_guard<std::mutex> lk(g_prof.mu);
     if (!g_prof.on || g_prof.used >= g_prof.cap) return;
+    if (!g_prof.only.empty() && g_prof.only != tag) return;
     int id = -1;
     for (size_t i = 0; i < g_prof.names.size(); ++i)
         if (g_prof.names[i] == tag) { id = (int)i; break; }
@@ -189,6 +191,12 @@ extern "C" int phonlp_profile_begin(int max_samples) {
     g_prof.cap = max_samples;
     g_prof.used = 0;
     g_prof.on = true;
+    return PHONLP_OK;
+}
+
+extern "C" int phonlp_profile_only(const char *tag) {
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    g_prof.only = tag ? tag : "";
     return PHONLP_OK;
 }
 

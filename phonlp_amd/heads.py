@@ -227,9 +227,9 @@ class TaskHeads:
                 tag_done.record(s_tag)
             return tag, ner, tag_done
 
-        # PHONLP_TAGGER_LATE=1 (A/B): start the tagger chain when the arc scores are done, beside the MST and stage A,
-        # instead of beside the parser's own POS head and arc GEMMs
-        tagger_late = os.environ.get("PHONLP_TAGGER_LATE", "0") == "1"
+        # The tagger chain starts when the arc scores are done, beside the MST and stage A (measured: 3.64 vs 3.71 ms
+        # per step); PHONLP_TAGGER_LATE=0 (A/B) starts it beside the parser's own POS head and arc GEMMs instead
+        tagger_late = os.environ.get("PHONLP_TAGGER_LATE", "1") == "1"
         if not tagger_late:
             tag, ner, tag_done = run_tagger(start)
         # parser chain up to the arc log-probs on the main stream

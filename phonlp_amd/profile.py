@@ -8,13 +8,17 @@ from ._lib import check, lib
 
 
 class KernelTimer:
-    """with KernelTimer(max_samples) as kt: ...launch work...;  kt.stats -> {tag: (count, mean_ms, min_ms)}"""
+    """with KernelTimer(max_samples) as kt: ...launch work...;  kt.stats -> {tag: (count, mean_ms, min_ms)}
 
-    def __init__(self, max_samples=8192):
+    `only`: sample the launches with this tag only (every sampled launch adds two event records to its queue)."""
+
+    def __init__(self, max_samples=8192, only=None):
         self.max_samples = max_samples
+        self.only = only
         self.stats = {}
 
     def __enter__(self):
+        check(lib().phonlp_profile_only(self.only.encode() if self.only else None), "phonlp_profile_only")
         check(lib().phonlp_profile_begin(self.max_samples), "phonlp_profile_begin")
         return self
 
