@@ -6,7 +6,8 @@ run() {
   python3 -c "
 import json,sys
 r=json.loads(open('gpurun_out/ab_tmp.json').read().strip().splitlines()[-1])
-print('%-40s %.3f ms/step  stageA %.3f  frac %.3f' % (sys.argv[1] or '(default)', r['ms_per_step'], r['roofline']['mean_ms'], r['roofline']['frac']))
+k=r['kernels_ms']
+print('%-40s %.3f ms/step  stageA %.3f  frac %.3f | %s' % (sys.argv[1] or '(default)', r['ms_per_step'], r['roofline']['mean_ms'], r['roofline']['frac'], ' '.join('%s %.3f' % (n.replace('linear:',''), v) for n, v in k.items() if n != 'linear:label_stage_a')))
 " "$1"
 }
 run "" && for v in "$@"; do run "$v" || exit 1; done
