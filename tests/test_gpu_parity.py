@@ -417,6 +417,39 @@ def test_synthetic_heads_vs_oracle(dev, engine, B, L, ragged):
     assert (h.cpu().numpy() != oh).mean() <= 0.002
 
 
+@pytest.mark.parametrize("B,L,lens1", [(1, 2, [2]), (1, 3, [3]), (2, 5, [5, 2]), (5, 9, [9, 7, 4, 2, 2]),
+                                       (3, 64, [64, 33, 2]), (1, 128, [128])])
+def test_tiny_and_ragged_batches_end_to_end(dev, engine, B, L, lens1):
+    """The smallest inputs annotate() can produce (one sentence of one word: ROOT + 1 node on the parser path, one
+    token on the tagger path) and ragged batches whose tail sentences have one word, through annotate_batch (three
+    streams, folded dep_hid, labels at the decoded heads) against the oracle chain end to end."""
+    from phonlp_amd import HeadWeights, TaskHeads
+    from phonlp_amd import synthetic as S
+    sd = S.make_state_dict()
+    enc_dep, enc_tag = S.make_encoder_outputs(B, L, seed=77 + B + L)
+    lens = [l - 1 for l in lens1]
+    heads = TaskHeads(HeadWeights.from_state_dict(sd, dev))
+    out = heads.annotate_batch(enc_dep.to(dev), lens1, enc_tag.to(dev), lens)
+    torch.cuda.synchronize()
+    od = O.dep_heads(enc_dep, lens1, sd)
+    ot = O.tagger_heads(enc_tag, lens, sd)
+    wh, ws = C.mst_batch(od["arc_logp"].numpy(), lens1)
+    assert not ws.any() and (out["mst_status"] == 0).all()
+    assert np.array_equal(out["heads"].cpu().numpy(), wh)
+    rel = np.zeros((B, L), np.int64)
+    for b in range(B):
+        for i in range(1, lens1[b]):
+            rel[b, i] = int(od["label_argmax"][b, i, wh[b, i]])
+    assert np.array_equal(out["rels"].cpu().numpy(), rel)
+    wt, _ = C.viterbi_batch(ot["ner_logits"].numpy(), sd["crit_ner._transitions"].numpy(), lens)
+    assert np.array_equal(out["ner"].cpu().numpy(), wt)
+    assert np.array_equal(out["pos"].cpu().numpy(), ot["pos_pred"].numpy())
+    # padding: zeros everywhere past the sentence
+    for b in range(B):
+        assert (out["heads"][b, lens1[b]:] == 0).all() and (out["rels"][b, lens1[b]:] == 0).all()
+        assert (out["ner"][b, lens[b]:] == 0).all() and (out["pos"][b, lens[b]:] == 0).all()
+
+
 def test_headline_batch_properties(dev, engine):
     """B=256, L=128 (BASELINE config 3): sentences are independent, so any sub-batch must reproduce the big
     batch bit-for-bit; decoded trees must be single-rooted and acyclic; decoders match the C oracle."""
