@@ -121,6 +121,20 @@ int phonlp_pos_head_split(const float *enc, int ld_enc, const int32_t *sentlens,
                           int H, int U, int TE, float *feat_opt, void *feat_planes, float *feat_inv_scale,
                           int32_t *pos_pred, float *upos_logits, void *ws, size_t ws_bytes, void *stream);
 
+/* Fused tagger head -- annotate_model.py:132-150 (tagger_forward after the gather) in one call, without forming
+ * feat = [enc | pos_emb]: since ner_tag_clf is linear in feat,
+ *   ner_logits = pad(relu(Wner[:, :E] . enc + Wner[:, E:] . pos_emb + bner)),
+ * the enc part rides along the upos_hid GEMM as T extra output columns and the embedding part is added in the tail
+ * kernel.  Whn [H+T, E] = upos_hid.weight rows followed by ner_tag_clf.weight[:, :E]; bhn [H+T] = upos_hid.bias followed
+ * by zeros; Wner_emb [T, TE] = ner_tag_clf.weight[:, E:]; emb = upos_emb_matrix_ner [U, TE].  Same results as
+ * phonlp_pos_head + phonlp_ner_emission to fp32 rounding (the 868-term dot product is summed in another order).
+ * pos_pred [B*L], ner_logits [B*L, T]; upos_logits [B*L, U] optional (NULL to skip). */
+size_t phonlp_tagger_head_ws_bytes(int B, int L, int E, int H, int U, int TE, int T);
+int phonlp_tagger_head(const float *enc, int ld_enc, const int32_t *sentlens, int B, int L, int E,
+                       const float *Whn, const float *bhn, const float *Wclf, const float *bclf, const float *emb,
+                       const float *Wner_emb, const float *bner, int H, int U, int TE, int T,
+                       int32_t *pos_pred, float *ner_logits, float *upos_logits, void *ws, size_t ws_bytes, void *stream);
+
 /* NER emissions -- annotate_model.py:149-150: logits[B,L,T] = pad(relu(feat . Wner^T + bner)). */
 int phonlp_ner_emission(const float *feat, int D, const int32_t *sentlens, int B, int L,
                         const float *Wner, const float *bner, int T, float *logits, void *stream);

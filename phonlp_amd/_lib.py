@@ -24,6 +24,8 @@ SIGNATURES = {
     "phonlp_pos_head_ws_bytes": (_z, [_i, _i, _i, _i, _i, _i]),
     "phonlp_pos_head": (_i, [_p, _i, _p, _i, _i, _i, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _z, _p]),
     "phonlp_pos_head_split": (_i, [_p, _i, _p, _i, _i, _i, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _z, _p]),
+    "phonlp_tagger_head_ws_bytes": (_z, [_i, _i, _i, _i, _i, _i, _i]),
+    "phonlp_tagger_head": (_i, [_p, _i, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _z, _p]),
     "phonlp_ner_emission": (_i, [_p, _i, _p, _i, _i, _p, _p, _i, _p, _p]),
     "phonlp_dep_hidden": (_i, [_p, _i, _p, _i, _i, _p, _p, _p, _p]),
     "phonlp_biaffine_arc_ws_bytes": (_z, [_i, _i, _i, _i]),

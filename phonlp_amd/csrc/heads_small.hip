@@ -175,6 +175,71 @@ __global__ __launch_bounds__(256) void pos_tail_kernel(const float *enc, long ld
     }
 }
 
+
+// Tail of the fused tagger head (phonlp_tagger_head): one wavefront per token.  logits [M, U] -> pos_pred and the soft POS
+// embedding e = softmax(logits) . emb as in pos_tail_kernel; then the NER emissions
+//   ner[t] = relu(hid[tok][H + t] + e . Wne[t] + bner[t]),
+// where hid's columns H.. hold ner_tag_clf.weight[:, :E] . enc (computed by the upos_hid GEMM as T extra output
+// columns) and Wne = ner_tag_clf.weight[:, E:]: ref annotate_model.py:138-150 without ever forming [enc | e].
+__global__ __launch_bounds__(256) void tagger_tail_kernel(const float *hid, long ldh, const float *logits, const float *emb,
+                                                          const float *Wne, const float *bner, const int32_t *sentlens,
+                                                          int M, int L, int H, int U, int TE, int T, int32_t *pos_pred,
+                                                          float *ner) {
+    extern __shared__ __attribute__((aligned(16))) float rows[];
+    const int lane = threadIdx.x & 63;
+    const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tok >= M) return;
+    float *e = rows + (threadIdx.x >> 6) * TE;
+    const int b = tok / L, i = tok % L;
+    if (i >= sentlens[b]) {  // padding: pad_packed_sequence zeros, arg-max of a zero row = 0
+        if (lane == 0) pos_pred[tok] = 0;
+        for (int t = lane; t < T; t += 64) ner[(long)tok * T + t] = 0.f;
+        return;
+    }
+    const float x = lane < U ? logits[(long)tok * U + lane] : -INFINITY;
+    float best = x;
+    int bi = lane;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float v2 = __shfl_xor(best, o);
+        const int i2 = __shfl_xor(bi, o);
+        if (v2 > best || (v2 == best && i2 < bi)) { best = v2; bi = i2; }
+    }
+    if (lane == 0) pos_pred[tok] = bi;
+    float p = lane < U ? expf(x - best) : 0.f;
+    float s = p;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    p = p / s;
+    for (int d = lane; d < TE; d += 64) {
+        float acc = 0.f;
+        for (int u = 0; u < U; ++u) acc += __shfl(p, u) * emb[u * TE + d];
+        e[d] = acc;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // e . Wne[t]: G = 64 / T lanes per tag, lane (t, g) sums the d = g (mod G) terms; the G shares of a tag are added in
+    // ascending g by one lane (a fixed order: deterministic).  More than 64 tags: passes of 64 with one lane per tag.
+    float *share = rows + 4 * TE + (threadIdx.x >> 6) * 64;
+    const int Tc = T < 64 ? T : 64, G = 64 / Tc;
+    for (int t0 = 0; t0 < T; t0 += Tc) {
+        const int tl = lane / G, g = lane - tl * G, t = t0 + tl;
+        float part = 0.f;
+        if (tl < Tc && t < T) {
+            const float *w = Wne + (long)t * TE;
+            for (int d = g; d < TE; d += G) part = fmaf(e[d], w[d], part);
+        }
+        share[lane] = part;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (lane < Tc && t0 + lane < T) {
+            float dot = 0.f;
+            for (int g2 = 0; g2 < G; ++g2) dot += share[lane * G + g2];
+            const float v = (hid[(long)tok * ldh + H + t0 + lane] + dot) + bner[t0 + lane];
+            ner[(long)tok * T + t0 + lane] = fmaxf(v, 0.f);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+}
+
 }  // namespace phonlp
 
 using namespace phonlp;
@@ -307,6 +372,60 @@ extern "C" int phonlp_pos_head_split(const float *enc, int ld_enc, const int32_t
     if (!feat_planes) return fail(PHONLP_ERR_SHAPE, "pos_head_split: feat_planes is required");
     return pos_head_impl(enc, ld_enc, sentlens, B, L, E, Whid, bhid, Wclf, bclf, emb, H, U, TE, feat_opt, pos_pred,
                          upos_logits, feat_planes, feat_inv_scale, ws, ws_bytes, stream);
+}
+
+/* Fused tagger head: POS head + NER emissions with feat = [enc | pos_emb] never materialised. */
+extern "C" size_t phonlp_tagger_head_ws_bytes(int B, int L, int E, int H, int U, int TE, int T) {
+    (void)TE;
+    const size_t M = (size_t)B * L, HN = (size_t)(H + T + 3) / 4 * 4;
+    return align_up(M * HN * sizeof(float), 256) + align_up(M * U * sizeof(float), 256) +
+           align_up(phonlp_split_bytes((int)M, E), 256) + align_up(M * sizeof(float), 256) +
+           align_up(phonlp_split_bytes(H + T, E), 256) + align_up((size_t)(H + T) * sizeof(float), 256);
+}
+
+extern "C" int phonlp_tagger_head(const float *enc, int ld_enc, const int32_t *sentlens, int B, int L, int E,
+                                  const float *Whn, const float *bhn, const float *Wclf, const float *bclf,
+                                  const float *emb, const float *Wner_emb, const float *bner, int H, int U, int TE, int T,
+                                  int32_t *pos_pred, float *ner_logits, float *upos_logits, void *ws, size_t ws_bytes,
+                                  void *stream) {
+    if (!enc || !sentlens || !Whn || !bhn || !Wclf || !bclf || !emb || !Wner_emb || !bner || !pos_pred || !ner_logits ||
+        B <= 0 || L <= 0 || T <= 0)
+        return fail(PHONLP_ERR_SHAPE, "tagger_head: bad argument");
+    if (U > 64 || U <= 0) return fail(PHONLP_ERR_UNSUPPORTED, "tagger_head: needs 1 <= U <= 64 (one lane per tag)");
+    if ((E & 3) || (H & 3) || (ld_enc & 3)) return fail(PHONLP_ERR_SHAPE, "tagger_head: E, H, ld_enc must be multiples of 4");
+    if (!ws || ws_bytes < phonlp_tagger_head_ws_bytes(B, L, E, H, U, TE, T))
+        return fail(PHONLP_ERR_WORKSPACE, "tagger_head: workspace too small");
+    if ((size_t)4 * TE * sizeof(float) > 64 * 1024) return fail(PHONLP_ERR_UNSUPPORTED, "tagger_head: TE too large");
+    hipStream_t st = as_stream(stream);
+    const int M = B * L, N = H + T, HN = (N + 3) / 4 * 4;
+    char *p = (char *)ws;
+    float *hid = (float *)p;       p += align_up((size_t)M * HN * sizeof(float), 256);
+    float *lg_ws = (float *)p;     p += align_up((size_t)M * U * sizeof(float), 256);
+    float *logits = upos_logits ? upos_logits : lg_ws;
+    int rc;
+    // upos_hid and the enc part of ner_tag_clf as ONE GEMM: N = H + T output columns, ReLU on the first H only
+    if (gemm_engine() == 2 && (E % 8) == 0) {
+        void *encp = p;             p += align_up(phonlp_split_bytes(M, E), 256);
+        float *enci = (float *)p;   p += align_up((size_t)M * sizeof(float), 256);
+        void *whp = p;              p += align_up(phonlp_split_bytes(N, E), 256);
+        float *whi = (float *)p;
+        const int K16e = (E + 15) / 16 * 16;
+        rc = launch_split_rows(enc, ld_enc, M, E, encp, 0, enci, st);
+        if (rc) return rc;
+        rc = launch_split_rows(Whn, E, N, E, whp, 0, whi, st);
+        if (rc) return rc;
+        rc = launch_linear_f16x3("linear:upos_hid", encp, 4L * K16e, enci, whp, 4L * K16e, whi, bhn, hid, HN, M, N, K16e, -H,
+                                 sentlens, L, st, nullptr);
+    } else {
+        rc = launch_linear("linear:upos_hid", enc, ld_enc, Whn, E, bhn, hid, HN, M, N, E, -H, sentlens, L, st);
+    }
+    if (rc) return rc;
+    rc = launch_linear("linear:upos_clf", hid, HN, Wclf, H, bclf, logits, U, M, U, H, 0, sentlens, L, st);
+    if (rc) return rc;
+    ProfScope ps("tagger_tail", st);
+    hipLaunchKernelGGL(tagger_tail_kernel, dim3(ceil_div(M, 4)), dim3(256), 4 * (size_t)(TE + 64) * sizeof(float), st, hid, (long)HN,
+                       logits, emb, Wner_emb, bner, sentlens, M, L, H, U, TE, T, pos_pred, ner_logits);
+    return check_launch("tagger_tail_kernel");
 }
 
 extern "C" int phonlp_ner_emission(const float *feat, int D, const int32_t *sentlens, int B, int L, const float *Wner,

@@ -1,5 +1,7 @@
 // Arguments and the shared epilogue of the dense-layer kernels (linear.hip, linear_f16x3.hip).
 #pragma once
+#include <limits.h>
+
 #include "mma_f32.h"
 
 namespace phonlp {
@@ -13,7 +15,7 @@ struct LinearArgs {
     const int32_t *sentlens;
     long ldx, ldw, ldy;
     int M, N, K, L;
-    int relu;
+    int relu;   // 0: none; 1: ReLU on every column; -n (internal callers): ReLU on the first n columns only
     int num_m, num_n;
     // engine 2 only (linear_f16x3.hip): per-row / per-column powers of two that undo the operand scaling
     const float *row_scale, *col_scale;
@@ -67,13 +69,20 @@ __device__ __forceinline__ void linear_epilogue(f32x16 (&acc)[TM][TN], float *ld
                 if (col + 2 < a.N) cs.z = a.col_scale[col + 2];
                 if (col + 3 < a.N) cs.w = a.col_scale[col + 3];
             }
+            // ReLU as a per-column lower clamp: 0 where it applies, -inf elsewhere
+            const int relu_n = a.relu > 0 ? INT_MAX : -a.relu;
+            float4 lo;
+            lo.x = col < relu_n ? 0.f : -INFINITY;
+            lo.y = col + 1 < relu_n ? 0.f : -INFINITY;
+            lo.z = col + 2 < relu_n ? 0.f : -INFINITY;
+            lo.w = col + 3 < relu_n ? 0.f : -INFINITY;
             float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);  // value of a padded row
             if (a.pad_bias) {
                 if (col < a.N) pv.x = a.pad_bias[col];
                 if (col + 1 < a.N) pv.y = a.pad_bias[col + 1];
                 if (col + 2 < a.N) pv.z = a.pad_bias[col + 2];
                 if (col + 3 < a.N) pv.w = a.pad_bias[col + 3];
-                if (a.relu) { pv.x = fmaxf(pv.x, 0.f); pv.y = fmaxf(pv.y, 0.f); pv.z = fmaxf(pv.z, 0.f); pv.w = fmaxf(pv.w, 0.f); }
+                if (a.relu) { pv.x = fmaxf(pv.x, lo.x); pv.y = fmaxf(pv.y, lo.y); pv.z = fmaxf(pv.z, lo.z); pv.w = fmaxf(pv.w, lo.w); }
             }
             unsigned live[TM];
     #pragma unroll
@@ -105,7 +114,7 @@ __device__ __forceinline__ void linear_epilogue(f32x16 (&acc)[TM][TN], float *ld
                         v.x = v.x * rs * cs.x; v.y = v.y * rs * cs.y; v.z = v.z * rs * cs.z; v.w = v.w * rs * cs.w;
                     }
                     v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-                    if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    if (a.relu) { v.x = fmaxf(v.x, lo.x); v.y = fmaxf(v.y, lo.y); v.z = fmaxf(v.z, lo.z); v.w = fmaxf(v.w, lo.w); }
                     if (!((live[i] >> it) & 1u)) v = pv;
                     if (row >= a.M || col >= a.N) continue;
                     if (a.dbg == 1 && v.x != 1234.5f) continue;

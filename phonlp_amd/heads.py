@@ -57,6 +57,10 @@ class HeadWeights:
     lab_W12f_s: Optional[tuple] = None
     lab_Wbt_s: Optional[tuple] = None
     lab_Wbtc_s: Optional[tuple] = None  # the same with every relation's rows padded to a multiple of 32 (fused form)
+    # fused tagger head (ops.tagger_head): upos_hid rows followed by the enc columns of ner_tag_clf; its embedding columns
+    tag_Whn: Optional[torch.Tensor] = None
+    tag_bhn: Optional[torch.Tensor] = None
+    ner_w_emb: Optional[torch.Tensor] = None
 
     @classmethod
     def from_state_dict(cls, sd: Dict[str, torch.Tensor], device="cuda", linearization=True, distance=True):
@@ -86,6 +90,7 @@ class HeadWeights:
 
         H = sd["unlabeled.W1.weight"].shape[0]
         O = sd["deprel.scorer.W_bilin.weight"].shape[2]
+        E_ = sd["upos_hid.weight"].shape[1]  # encoder width
         if linearization or distance:
             # the arc kernel keeps one slot per scorer; a disabled scorer gets zero weights and is ignored
             packs = []
@@ -120,6 +125,9 @@ class HeadWeights:
             arc_W12f_s=tuple(ops.split_rows(arcf[0])), lab_W12f_s=tuple(ops.split_rows(labf[0])),
             lab_Wbt_s=tuple(ops.split_rows(lab[2])),
             lab_Wbtc_s=tuple(ops.split_rows(cls._pad_relations(lab[2], H, O))),
+            tag_Whn=torch.cat([g("upos_hid.weight"), g("ner_tag_clf.weight")[:, :E_]], 0).contiguous(),
+            tag_bhn=torch.cat([g("upos_hid.bias"), torch.zeros_like(g("ner_tag_clf.bias"))], 0).contiguous(),
+            ner_w_emb=g("ner_tag_clf.weight")[:, E_:].contiguous(),
         )
 
     @staticmethod
@@ -221,7 +229,12 @@ class TaskHeads:
         def run_tagger(after):
             s_tag.wait_event(after)
             with torch.cuda.stream(s_tag):
-                tag = self.tagger(enc_tag, lens_t)
+                if os.environ.get("PHONLP_TAGGER_FUSED", "1") == "1":  # A/B switch: 0 = pos_head + ner_emission
+                    pos_pred, ner_logits, _ = ops.tagger_head(enc_tag.contiguous(), lens_t, w.tag_Whn, w.tag_bhn,
+                                                              w.upos_clf_w, w.upos_clf_b, w.emb_ner, w.ner_w_emb, w.ner_b)
+                    tag = {"pos_pred": pos_pred, "ner_logits": ner_logits}
+                else:
+                    tag = self.tagger(enc_tag, lens_t)
                 ner, _ = ops.crf_viterbi(tag["ner_logits"], w.trans, lens_t)
                 tag_done = torch.cuda.Event()
                 tag_done.record(s_tag)

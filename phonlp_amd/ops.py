@@ -103,6 +103,28 @@ def pos_head(enc: Tensor, sentlens: Tensor, Whid: Tensor, bhid: Tensor, Wclf: Te
     return feat, pos, logits
 
 
+@torch.library.custom_op("phonlp_amd::tagger_head", mutates_args=())
+def tagger_head(enc: Tensor, sentlens: Tensor, Whn: Tensor, bhn: Tensor, Wclf: Tensor, bclf: Tensor, emb: Tensor,
+                Wner_emb: Tensor, bner: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+    """Fused tagger head (ref annotate_model.py:132-150): enc [B,L,E] -> (pos_pred int32 [B,L], ner_logits [B,L,T],
+    upos_logits [B,L,U]); Whn / bhn / Wner_emb as HeadWeights packs them (include/phonlp_heads.h)."""
+    _need(enc, torch.float32, "enc")
+    _need(sentlens, torch.int32, "sentlens")
+    B, L, E = enc.shape
+    U, TE, T = Wclf.shape[0], emb.shape[1], Wner_emb.shape[0]
+    H = Whn.shape[0] - T
+    dev = enc.device
+    pos = torch.empty((B, L), dtype=torch.int32, device=dev)
+    ner = torch.empty((B, L, T), dtype=torch.float32, device=dev)
+    logits = torch.empty((B, L, U), dtype=torch.float32, device=dev)
+    nb = lib().phonlp_tagger_head_ws_bytes(B, L, E, H, U, TE, T)
+    ws = _ws(nb, dev)
+    check(lib().phonlp_tagger_head(_p(enc), E, _p(sentlens), B, L, E, _p(Whn), _p(bhn), _p(Wclf), _p(bclf), _p(emb),
+                                   _p(Wner_emb), _p(bner), H, U, TE, T, _p(pos), _p(ner), _p(logits), _p(ws), nb,
+                                   _stream()), "phonlp_tagger_head")
+    return pos, ner, logits
+
+
 @torch.library.custom_op("phonlp_amd::ner_emission", mutates_args=())
 def ner_emission(feat: Tensor, sentlens: Tensor, Wner: Tensor, bner: Tensor) -> Tensor:
     _need(feat, torch.float32, "feat")

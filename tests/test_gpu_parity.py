@@ -621,6 +621,34 @@ def test_pos_head_split_image(dev, B, L, E, TE, H, U, emb_scale):
             assert torch.equal(feat1, feat0)
 
 
+@pytest.mark.parametrize("B,L,E,TE,H,U,T", [(7, 33, 64, 12, 24, 7, 5), (5, 19, 24, 8, 16, 7, 3), (2, 4, 20, 4, 8, 3, 70),
+                                             (16, 127, 768, 100, 400, 24, 9)])
+def test_fused_tagger_head(dev, engine, B, L, E, TE, H, U, T):
+    """ops.tagger_head (upos_hid and the enc columns of ner_tag_clf in one GEMM, embedding columns added in the tail,
+    feat never formed) against pos_head + ner_emission and against the oracle (ref annotate_model.py:132-150):
+    POS ids equal, emissions to fp32 rounding, padded rows exact zeros."""
+    from phonlp_amd import HeadWeights, TaskHeads, ops
+    from phonlp_amd import synthetic as S
+    sd = S.make_state_dict(E, TE, H, U, 5, T, seed=B + T)
+    w = HeadWeights.from_state_dict(sd, dev)
+    g = torch.Generator().manual_seed(L)
+    enc = torch.randn(B, L, E, generator=g)
+    lens = torch.randint(1, L + 1, (B,), generator=g).sort(descending=True)[0].to(torch.int32)
+    lens[0] = L
+    lens_d = lens.to(dev)
+    pos, ner, logits = ops.tagger_head(enc.to(dev), lens_d, w.tag_Whn, w.tag_bhn, w.upos_clf_w, w.upos_clf_b, w.emb_ner,
+                                       w.ner_w_emb, w.ner_b)
+    ref = TaskHeads(w).tagger(enc.to(dev), lens_d)
+    assert torch.equal(pos, ref["pos_pred"])
+    _close(logits, ref["upos_logits"], rtol=1e-5, atol=1e-6)
+    _close(ner, ref["ner_logits"], rtol=1e-5, atol=2e-6)
+    ot = O.tagger_heads(enc, lens.tolist(), sd)
+    _close(ner, ot["ner_logits"], rtol=1e-4, atol=1e-5)
+    _near_tie_ok(pos.cpu(), ot["pos_pred"], ot["upos_logits"], 1e-5)
+    live = torch.arange(L)[None, :] < lens[:, None]
+    assert (ner.cpu()[~live] == 0).all() and (pos.cpu()[~live] == 0).all()
+
+
 def test_streaming_batches_match_joined(dev):
     """annotate_batch(join=False) on back-to-back batches (tails on the finishing stream, next batch's GEMMs not
     waiting for the MST) gives exactly the outputs of the joined form."""
