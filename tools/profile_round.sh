@@ -40,7 +40,7 @@ for k, c in sorted(acc.items()):
     gui = sum(c["GRBM_GUI_ACTIVE"]) / len(c["GRBM_GUI_ACTIVE"])
     if busy <= 0: continue
     mf.append({"kernel": k, "mfma_busy_cycles_per_launch": busy, "gpu_cycles_per_launch": gui,
-               "mfma_pipe_util": busy / (1024.0 * gui),
+               "mfma_pipe_util": busy / (1024.0 * gui / 8.0),
                "mops_bf16": sum(c.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", [0])) / max(len(c.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", [0])), 1),
                "mops_f16": sum(c.get("SQ_INSTS_VALU_MFMA_MOPS_F16", [0])) / max(len(c.get("SQ_INSTS_VALU_MFMA_MOPS_F16", [0])), 1),
                "mops_f32": sum(c.get("SQ_INSTS_VALU_MFMA_MOPS_F32", [0])) / max(len(c.get("SQ_INSTS_VALU_MFMA_MOPS_F32", [0])), 1)})
@@ -48,8 +48,9 @@ stats = glob.glob(f"{out}/stats/**/*kernel_stats.csv", recursive=True)
 summary = {"_how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over python3 bench.py --steps 3 --warmup 1 "
                    "--no-cpu-baseline; per-launch mean; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (MI355X_MICROARCH.md: FETCH_SIZE "
                    "reports half of a wide coalesced read on gfx950, WRITE_SIZE is exact)", "per_kernel": per,
-           "_mfma_how": "separate pass --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE ...; util = busy / (1024 SIMDs * GRBM_GUI_ACTIVE); "
-                        "kernels of different streams overlap in the step, so GRBM_GUI_ACTIVE of a kernel includes time it shared the chip",
+           "_mfma_how": "separate pass --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE ...; util = busy / (1024 SIMDs * GRBM_GUI_ACTIVE / 8): "
+                        "GRBM_GUI_ACTIVE comes summed over the 8 XCCs; counter collection serialises the launches, so every kernel is alone "
+                        "on the chip in this pass",
            "mfma": mf}
 json.dump(summary, open(f"{out}/summary.json", "w"), indent=1)
 print(open(stats[0]).read()[:3000])
