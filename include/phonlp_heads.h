@@ -205,10 +205,12 @@ int phonlp_label_at_heads(const float *T, const float *XF, const int32_t *heads,
  * (X1p/x1_inv: phonlp_split_rows of XF[:, 0:KP]; Wbtp/wbt_inv: of the phonlp_pack_bilinear image) and writes T in the
  * "rows interleaved by 4" layout T4[(m/4)*O*KP + c][m%4] = T[m][c] (phonlp_label_t4_bytes bytes), which is the order
  * the MFMA accumulators hold it in; phonlp_label_at_heads_rows4 is phonlp_label_at_heads reading that layout
- * (same fp32 dot products in another summation order: equal to rounding). */
+ * (same fp32 dot products in another summation order: equal to rounding).  ones_col: NULL, or [O*KP] = column H of the
+ * phonlp_pack_bilinear image (Wbt[c][H], the weights that meet X1's ones column): the term is then added per column in
+ * the epilogue instead of inside the product, which saves a k16 stage when H % 16 == 0. */
 size_t phonlp_label_t4_bytes(int B, int L, int H, int O);
 int phonlp_label_stage_a_split(const void *X1p, const float *x1_inv, const void *Wbtp, const float *wbt_inv,
-                               int B, int L, int H, int O, float *T4, void *stream);
+                               const float *ones_col, int B, int L, int H, int O, float *T4, void *stream);
 int phonlp_label_at_heads_rows4(const float *T4, const float *XF, const int32_t *heads, const int32_t *sentlens,
                                 int B, int L, int H, int O, int32_t *rels, float *best_opt, void *stream);
 

@@ -42,7 +42,7 @@ SIGNATURES = {
     "phonlp_label_project": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "phonlp_label_at_heads": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p]),
     "phonlp_label_t4_bytes": (_z, [_i, _i, _i, _i]),
-    "phonlp_label_stage_a_split": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p]),
+    "phonlp_label_stage_a_split": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p]),
     "phonlp_label_at_heads_rows4": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p]),
     "phonlp_label_kpc": (_i, [_i]),
     "phonlp_label_at_heads_fused_ws_bytes": (_z, [_i, _i, _i, _i]),

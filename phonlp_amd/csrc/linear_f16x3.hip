@@ -84,17 +84,18 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float *X, long ld
 // Epilogue in the "rows interleaved by 4" layout: Y4[(m/4)*N + n][m%4] = C[m][n].  In the MFMA C/D layout four
 // consecutive accumulator registers of a lane are four consecutive ROWS of one column, so a lane's float4 is stored
 // as it stands (no LDS transpose): lanes 0-31 of a wave-store write 512 contiguous bytes, lanes 32-63 the next row
-// group's 512.  Only scaling (exact powers of two); no bias / activation / padding in this form.  Y4 holds
+// group's 512.  Scaling (exact powers of two) and an optional per-column bias; no activation / padding in this form.  Y4 holds
 // ceil(M/4) row groups, so a group that straddles M is stored whole.
 template <int TM, int TN>
 __device__ __forceinline__ void rows4_epilogue(f32x16 (&acc)[TM][TN], const LinearArgs &a, int m0, int n0, int wm, int wn,
                                                int lane) {
-    float cs[TN];
+    float cs[TN], cb[TN];
     int col[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         col[j] = n0 + (wn * TN + j) * 32 + (lane & 31);
         cs[j] = (a.col_scale && col[j] < a.N) ? a.col_scale[col[j]] : 1.f;
+        cb[j] = (a.bias && col[j] < a.N) ? a.bias[col[j]] : 0.f;  // per-column term added to all four rows
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -113,10 +114,10 @@ __device__ __forceinline__ void rows4_epilogue(f32x16 (&acc)[TM][TN], const Line
             for (int j = 0; j < TN; ++j) {
                 if (col[j] >= a.N) continue;
                 float4 v;
-                v.x = acc[i][j][4 * g + 0] * rs.x * cs[j];
-                v.y = acc[i][j][4 * g + 1] * rs.y * cs[j];
-                v.z = acc[i][j][4 * g + 2] * rs.z * cs[j];
-                v.w = acc[i][j][4 * g + 3] * rs.w * cs[j];
+                v.x = acc[i][j][4 * g + 0] * rs.x * cs[j] + cb[j];
+                v.y = acc[i][j][4 * g + 1] * rs.y * cs[j] + cb[j];
+                v.z = acc[i][j][4 * g + 2] * rs.z * cs[j] + cb[j];
+                v.w = acc[i][j][4 * g + 3] * rs.w * cs[j] + cb[j];
                 if (a.dbg == 1 && v.x != 1234.5f) continue;
                 *reinterpret_cast<float4 *>(a.Y + ((long)(row >> 2) * a.N + col[j]) * 4) = v;
             }
@@ -679,8 +680,8 @@ int launch_linear_f16x3(const char *tag, const void *Xp, long pitch_x, const flo
         a.x2 = at_heads->x2; a.hrow = at_heads->hrow; a.P = at_heads->P; a.ldx2 = at_heads->ldx2;
         a.kpc = at_heads->kpc; a.kpx = at_heads->kpx;
     }
-    if (rows4 == 1 && (bias || sentlens || relu || ((uintptr_t)Y & 15)))
-        return fail(PHONLP_ERR_SHAPE, "linear_split: the rows-by-4 output takes no bias / activation / padding mask");
+    if (rows4 == 1 && (sentlens || relu || ((uintptr_t)Y & 15)))
+        return fail(PHONLP_ERR_SHAPE, "linear_split: the rows-by-4 output takes no activation / padding mask");
     if (batch) {  // the fragment-at-stage kernel takes batched launches; the others do not
         if (batch->n < 1 || (batch->bsx & 15) || (batch->bsw & 15) || rows4 || at_heads)
             return fail(PHONLP_ERR_SHAPE, "linear_split: bad batch");
@@ -760,11 +761,15 @@ extern "C" size_t phonlp_label_t4_bytes(int B, int L, int H, int O) {
 }
 
 extern "C" int phonlp_label_stage_a_split(const void *X1p, const float *x1_inv, const void *Wbtp, const float *wbt_inv,
-                                          int B, int L, int H, int O, float *T4, void *stream) {
+                                          const float *ones_col, int B, int L, int H, int O, float *T4, void *stream) {
     if (B <= 0 || L <= 0 || H <= 0 || O <= 0) return fail(PHONLP_ERR_SHAPE, "label_stage_a_split: bad argument");
     const int KP = kp_of(H), K16 = (KP + 15) / 16 * 16;
-    return launch_linear_f16x3("linear:label_stage_a", X1p, 4L * K16, x1_inv, Wbtp, 4L * K16, wbt_inv, nullptr, T4, 0, B * L,
-                               O * KP, K16, 0, nullptr, 0, as_stream(stream), nullptr, 1);
+    // X1's ones column (index H) times row H of the bilinear weight is a per-column constant: given as ones_col it is
+    // added in the epilogue and the product runs over the H real features only -- a k16 stage less when H % 16 == 0
+    // (H = 400: 25 stages instead of 26)
+    const bool drop = ones_col && (H % 16) == 0;
+    return launch_linear_f16x3("linear:label_stage_a", X1p, 4L * K16, x1_inv, Wbtp, 4L * K16, wbt_inv, drop ? ones_col : nullptr,
+                               T4, 0, B * L, O * KP, drop ? H : K16, 0, nullptr, 0, as_stream(stream), nullptr, 1);
 }
 
 /* Labels at the decoded heads with stage A fused in: T never reaches memory. */

@@ -645,6 +645,12 @@ __global__ __launch_bounds__(256) void mst_wave_kernel(MstArgs a, int stack_cap)
 #undef SM
 }
 
+// Clears the shared-candidate region at the head of a launch (hipMemsetAsync's fill kernel takes ~85 us for these
+// 130 KB when other streams are busy; this one is a plain grid-stride store).
+__global__ void mst_clear_kernel(int32_t *p, int n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0;
+}
+
 int launch_mst_wave(MstArgs a, hipStream_t stream) {
     const WaveLayout w = wave_layout(a.L);
     static bool attr_set = false;
@@ -661,8 +667,11 @@ int launch_mst_wave(MstArgs a, hipStream_t stream) {
     static const int waiters = getenv("PHONLP_MST_WAITERS") ? atoi(getenv("PHONLP_MST_WAITERS")) : 0;
     a.max_waiters = waiters;
     // the queue, its counters and the per-sentence candidate counts start at zero in every launch
-    if (hipMemsetAsync(a.ctr, 0, mst_share_zero_bytes(a.B, a.L), stream) != hipSuccess)
-        return fail(PHONLP_ERR_LAUNCH, "mst_one_root: cannot clear the candidate queue");
+    {
+        const int nz = (int)(mst_share_zero_bytes(a.B, a.L) / sizeof(int32_t));
+        hipLaunchKernelGGL(mst_clear_kernel, dim3(ceil_div(nz, 1024) < 64 ? ceil_div(nz, 1024) : 64), dim3(256), 0, stream, a.ctr, nz);
+        if (hipGetLastError() != hipSuccess) return fail(PHONLP_ERR_LAUNCH, "mst_one_root: cannot clear the candidate queue");
+    }
     if (a.L <= 64) hipLaunchKernelGGL(mst_wave_kernel<1>, dim3(a.B), dim3(256), w.total, stream, a, w.stack_cap);
     else if (a.L <= 128) hipLaunchKernelGGL(mst_wave_kernel<2>, dim3(a.B), dim3(256), w.total, stream, a, w.stack_cap);
     else hipLaunchKernelGGL(mst_wave_kernel<4>, dim3(a.B), dim3(256), w.total, stream, a, w.stack_cap);

@@ -61,6 +61,7 @@ class HeadWeights:
     tag_Whn: Optional[torch.Tensor] = None
     tag_bhn: Optional[torch.Tensor] = None
     ner_w_emb: Optional[torch.Tensor] = None
+    lab_ones_col: Optional[torch.Tensor] = None  # column H of lab_Wbt: the weights that meet X1's ones column
 
     @classmethod
     def from_state_dict(cls, sd: Dict[str, torch.Tensor], device="cuda", linearization=True, distance=True):
@@ -128,6 +129,7 @@ class HeadWeights:
             tag_Whn=torch.cat([g("upos_hid.weight"), g("ner_tag_clf.weight")[:, :E_]], 0).contiguous(),
             tag_bhn=torch.cat([g("upos_hid.bias"), torch.zeros_like(g("ner_tag_clf.bias"))], 0).contiguous(),
             ner_w_emb=g("ner_tag_clf.weight")[:, E_:].contiguous(),
+            lab_ones_col=lab[2][:, H].contiguous(),
         )
 
     @staticmethod
@@ -243,11 +245,14 @@ class TaskHeads:
         # The tagger chain starts when the arc scores are done, beside the MST and stage A (measured: 3.64 vs 3.71 ms
         # per step); PHONLP_TAGGER_LATE=0 (A/B) starts it beside the parser's own POS head and arc GEMMs instead
         tagger_late = os.environ.get("PHONLP_TAGGER_LATE", "1") == "1"
-        if not tagger_late:
+        split = ops.get_gemm_engine() == 2 and w.lab_Wbt_s is not None
+        # A/B ("2"): behind the label scorer's W1/W2 layer (engine 2 path only)
+        tagger_later = split and os.environ.get("PHONLP_TAGGER_LATE", "1") == "2"
+        tagger_late = tagger_late or os.environ.get("PHONLP_TAGGER_LATE", "1") == "2"
+        if not tagger_late and not tagger_later:
             tag, ner, tag_done = run_tagger(start)
         # parser chain up to the arc log-probs on the main stream
         B, Ld, D = enc_dep.shape[0], enc_dep.shape[1], enc_dep.shape[2] + w.emb_dep.shape[1]
-        split = ops.get_gemm_engine() == 2 and w.lab_Wbt_s is not None
         rows4 = fused = False
         # dep_hid is folded into the scorers' first layers (HeadWeights.from_state_dict): the scorers read `feat`
         if split:  # engine 2: the large layers run on split images; the POS head's tail writes feat as one directly
@@ -263,7 +268,7 @@ class TaskHeads:
                                                 w.linearization, w.distance, False, lens_d, w.arc_b12)
         arc_done = torch.cuda.Event()
         arc_done.record(main)
-        if tagger_late:
+        if tagger_late and not tagger_later:
             tag, ner, tag_done = run_tagger(arc_done)
         # MST beside the label scorer
         s_mst.wait_event(arc_done)
@@ -276,6 +281,10 @@ class TaskHeads:
             XF = ops.linear_split(featp, feati, w.lab_W12f_s[0], w.lab_W12f_s[1], w.lab_b12f, D, True, lens_d, Ld,
                                   w.lab_b12, 2)
             x1p, x1i = ops.split_rows(XF[:, :ops.kp(w.H)])
+            if tagger_later:
+                w12_done = torch.cuda.Event()
+                w12_done.record(main)
+                tag, ner, tag_done = run_tagger(w12_done)
             rows4 = os.environ.get("PHONLP_ROWS4", "1") != "0"  # A/B switch: row-major T
             # Fused form (stage A after the MST with the labels-at-heads contraction in its epilogue, T never stored):
             # off by default -- measured 4.33 vs 4.02 ms per step joined (the MST is then exposed on the critical path)
@@ -284,7 +293,8 @@ class TaskHeads:
             if fused:
                 T = x1p  # stage A runs after the MST, inside label_at_heads_fused (T never reaches memory)
             elif rows4:
-                T = ops.label_stage_a_split(x1p, x1i, w.lab_Wbt_s[0], w.lab_Wbt_s[1], B, Ld, w.H, w.O)  # T4 layout
+                ones_col = w.lab_ones_col if os.environ.get("PHONLP_ONES_COL", "1") == "1" else None  # A/B switch
+                T = ops.label_stage_a_split(x1p, x1i, w.lab_Wbt_s[0], w.lab_Wbt_s[1], B, Ld, w.H, w.O, ones_col)  # T4
             else:
                 T = ops.linear_split(x1p, x1i, w.lab_Wbt_s[0], w.lab_Wbt_s[1], None, ops.kp(w.H), False, None, 0, None, 1)
         else:

@@ -376,14 +376,20 @@ def biaffine_arc_scores(XF: Tensor, B: int, L: int, Wbt: Tensor, H: int, n_score
 
 @torch.library.custom_op("phonlp_amd::label_stage_a_split", mutates_args=())
 def label_stage_a_split(x1p: Tensor, x1_inv: Tensor, wbtp: Tensor, wbt_inv: Tensor, B: int, L: int, H: int,
-                        O: int) -> Tensor:
-    """Engine-2 stage A of the label scorer -> T4 (fp32, 'rows interleaved by 4': include/phonlp_heads.h)."""
+                        O: int, ones_col: Optional[Tensor] = None) -> Tensor:
+    """Engine-2 stage A of the label scorer -> T4 (fp32, 'rows interleaved by 4': include/phonlp_heads.h).
+    ones_col: column H of the packed bilinear weight ([O*KP], HeadWeights.lab_ones_col) or None."""
     _need(x1p, torch.uint8, "x1p")
     _need(wbtp, torch.uint8, "wbtp")
     if x1p.shape[0] != B * L or wbtp.shape[0] != O * kp(H) or x1p.shape[1] != wbtp.shape[1]:
         raise ValueError("label_stage_a_split: split images do not match B, L, H, O")
     T4 = torch.empty(lib().phonlp_label_t4_bytes(B, L, H, O) // 4, dtype=torch.float32, device=x1p.device)
-    check(lib().phonlp_label_stage_a_split(_p(x1p), _p(x1_inv), _p(wbtp), _p(wbt_inv), B, L, H, O, _p(T4), _stream()),
+    if ones_col is not None:
+        _need(ones_col, torch.float32, "ones_col")
+        if ones_col.numel() != O * kp(H):
+            raise ValueError("label_stage_a_split: ones_col must hold O*KP floats")
+    check(lib().phonlp_label_stage_a_split(_p(x1p), _p(x1_inv), _p(wbtp), _p(wbt_inv),
+                                           _p(ones_col) if ones_col is not None else None, B, L, H, O, _p(T4), _stream()),
           "phonlp_label_stage_a_split")
     return T4
 

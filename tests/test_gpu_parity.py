@@ -575,6 +575,12 @@ def test_label_rows4_pair_matches_row_major(dev, B, L, H, O):
     M4 = (M + 3) // 4 * 4
     back = T4.view(M4 // 4, O * KP, 4).permute(0, 2, 1).reshape(M4, O * KP)[:M]
     assert torch.equal(back, T)
+    # X1's ones column taken out of the product and added per column in the epilogue (one k16 stage less when
+    # H % 16 == 0): the same sums in another order
+    T4o = ops.label_stage_a_split(x1p, x1i, wp, wi, B, L, H, O, w.lab_ones_col)
+    torch.testing.assert_close(T4o, T4, rtol=1e-5, atol=1e-5 * float(T4.abs().max()))
+    if H % 16:
+        assert torch.equal(T4o, T4)
     r0, b0 = ops.label_at_heads(T, XF, heads_d, lens_d, H, O)
     r4, b4 = ops.label_at_heads_rows4(T4, XF, heads_d, lens_d, H, O)
     # ... and the fused form (stage A + contraction in one kernel, T never stored) gives the same again
