@@ -62,6 +62,11 @@ class HeadWeights:
     tag_bhn: Optional[torch.Tensor] = None
     ner_w_emb: Optional[torch.Tensor] = None
     lab_ones_col: Optional[torch.Tensor] = None  # column H of lab_Wbt: the weights that meet X1's ones column
+    # dep_hid AND the soft POS embedding folded into the scorers' first layers: input columns = [enc | tag probabilities]
+    # (split images; emb_eye [U, Up] makes the POS tail write the probabilities where it wrote the embedding)
+    arc_W12p_s: Optional[tuple] = None
+    lab_W12p_s: Optional[tuple] = None
+    emb_eye: Optional[torch.Tensor] = None
 
     @classmethod
     def from_state_dict(cls, sd: Dict[str, torch.Tensor], device="cuda", linearization=True, distance=True):
@@ -89,6 +94,28 @@ class HeadWeights:
             W2, b2 = fold(f"{name}.W2.weight", f"{name}.W2.bias")
             return ops.pack_scorer(W1, b1, W2, b2, g(f"{name}.scorer.W_bilin.weight"))[:2]
 
+        # The soft POS embedding is pos_dis @ upos_emb_matrix_dep (ref annotate_model.py:177-179) with pos_dis a
+        # U-vector, so W [x ; pos_dis E] = W[:, :768] x + (W[:, 768:] E^T) pos_dis: the scorers can read
+        # [x ; pos_dis] (768 + U columns, U padded to a multiple of 4) instead of [x ; pos_emb] (768 + 100) -- five
+        # k16 stages less per W1/W2 GEMM at U = 24.  Folded in float64 together with dep_hid, rounded to fp32 once.
+        emb64 = sd["upos_emb_matrix_dep"].detach().double().cpu()  # [U, TE]
+        U_ = emb64.shape[0]
+        Up = (U_ + 3) // 4 * 4
+
+        def fold_p(w_name, b_name):
+            W, b = sd[w_name].detach().double().cpu(), sd[b_name].detach().double().cpu()
+            Wf = W @ Wd64
+            Wp = torch.zeros((W.shape[0], E_ + Up), dtype=torch.float64)
+            Wp[:, :E_] = Wf[:, :E_]
+            Wp[:, E_:E_ + U_] = Wf[:, E_:] @ emb64.T
+            return (Wp.to(device=device, dtype=torch.float32).contiguous(),
+                    (W @ bd64 + b).to(device=device, dtype=torch.float32).contiguous())
+
+        def pack_folded_p(name):
+            W1, b1 = fold_p(f"{name}.W1.weight", f"{name}.W1.bias")
+            W2, b2 = fold_p(f"{name}.W2.weight", f"{name}.W2.bias")
+            return ops.pack_scorer(W1, b1, W2, b2, g(f"{name}.scorer.W_bilin.weight"))[0]
+
         H = sd["unlabeled.W1.weight"].shape[0]
         O = sd["deprel.scorer.W_bilin.weight"].shape[2]
         E_ = sd["upos_hid.weight"].shape[1]  # encoder width
@@ -96,22 +123,28 @@ class HeadWeights:
             # the arc kernel keeps one slot per scorer; a disabled scorer gets zero weights and is ignored
             packs = []
             fpacks = []
+            ppacks = []
             for name, on in zip(SCORERS, (True, linearization, distance)):
                 if on:
                     packs.append(pack(name))
                     fpacks.append(pack_folded(name))
+                    ppacks.append(pack_folded_p(name))
                 else:
                     packs.append(tuple(torch.zeros_like(t) for t in packs[0]))
                     fpacks.append(tuple(torch.zeros_like(t) for t in fpacks[0]))
+                    ppacks.append(torch.zeros_like(ppacks[0]))
             arc = tuple(torch.cat([p[k] for p in packs], 0).contiguous() for k in range(3))
             arcf = tuple(torch.cat([p[k] for p in fpacks], 0).contiguous() for k in range(2))
+            arcp = torch.cat(ppacks, 0).contiguous()
             n_arc = 3
         else:
             arc = pack("unlabeled")
             arcf = pack_folded("unlabeled")
+            arcp = pack_folded_p("unlabeled")
             n_arc = 1
         lab = pack("deprel")
         labf = pack_folded("deprel")
+        labp = pack_folded_p("deprel")
         return cls(
             upos_hid_w=g("upos_hid.weight"), upos_hid_b=g("upos_hid.bias"),
             upos_clf_w=g("upos_clf.weight"), upos_clf_b=g("upos_clf.bias"),
@@ -130,6 +163,8 @@ class HeadWeights:
             tag_bhn=torch.cat([g("upos_hid.bias"), torch.zeros_like(g("ner_tag_clf.bias"))], 0).contiguous(),
             ner_w_emb=g("ner_tag_clf.weight")[:, E_:].contiguous(),
             lab_ones_col=lab[2][:, H].contiguous(),
+            arc_W12p_s=tuple(ops.split_rows(arcp)), lab_W12p_s=tuple(ops.split_rows(labp)),
+            emb_eye=torch.eye(U_, Up, dtype=torch.float32, device=device).contiguous(),
         )
 
     @staticmethod
@@ -255,10 +290,16 @@ class TaskHeads:
         B, Ld, D = enc_dep.shape[0], enc_dep.shape[1], enc_dep.shape[2] + w.emb_dep.shape[1]
         rows4 = fused = False
         # dep_hid is folded into the scorers' first layers (HeadWeights.from_state_dict): the scorers read `feat`
+        arcW, labW = w.arc_W12f_s, w.lab_W12f_s
         if split:  # engine 2: the large layers run on split images; the POS head's tail writes feat as one directly
+            emb = w.emb_dep
+            if w.arc_W12p_s is not None and os.environ.get("PHONLP_POS_FOLD", "1") == "1":  # A/B switch
+                # the embedding is folded into the scorers' weights: the "feat" image is [enc | tag probabilities]
+                emb, arcW, labW = w.emb_eye, w.arc_W12p_s, w.lab_W12p_s
+                D = enc_dep.shape[2] + emb.shape[1]
             featp, feati, _, _, _ = ops.pos_head_split(enc_dep.contiguous(), lens_d, w.upos_hid_w, w.upos_hid_b,
-                                                       w.upos_clf_w, w.upos_clf_b, w.emb_dep, False)
-            XFa = ops.linear_split(featp, feati, w.arc_W12f_s[0], w.arc_W12f_s[1], w.arc_b12f, D, True, lens_d, Ld,
+                                                       w.upos_clf_w, w.upos_clf_b, emb, False)
+            XFa = ops.linear_split(featp, feati, arcW[0], arcW[1], w.arc_b12f, D, True, lens_d, Ld,
                                    w.arc_b12, 3)
             arc_logp = ops.biaffine_arc_scores(XFa, B, Ld, w.arc_Wbt, w.H, w.n_arc_scorers, w.linearization, w.distance)
         else:
@@ -278,7 +319,7 @@ class TaskHeads:
             mst_done = torch.cuda.Event()
             mst_done.record(s_mst)
         if split:
-            XF = ops.linear_split(featp, feati, w.lab_W12f_s[0], w.lab_W12f_s[1], w.lab_b12f, D, True, lens_d, Ld,
+            XF = ops.linear_split(featp, feati, labW[0], labW[1], w.lab_b12f, D, True, lens_d, Ld,
                                   w.lab_b12, 2)
             x1p, x1i = ops.split_rows(XF[:, :ops.kp(w.H)])
             if tagger_later:
