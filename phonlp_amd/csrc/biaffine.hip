@@ -9,18 +9,11 @@
 //       label: running arg-max over o kept in registers; the B x L x L x O tensor never exists.
 #include <stdlib.h>
 
-#include "linear_args.h"
+#include "mma_f32.h"
 
 namespace phonlp {
 
 int gemm_engine();
-// engine 2 (linear_f16x3.hip)
-int launch_split_rows(const float *X, long ldx, int rows, int K, void *planes, long pitch, float *inv_scale, hipStream_t stream,
-                      int nbatch = 1, long bx = 0);
-int launch_linear_f16x3(const char *tag, const void *Xp, long pitch_x, const float *x_inv, const void *Wp, long pitch_w,
-                        const float *w_inv, const float *bias, float *Y, long ldy, int M, int N, int K16, int relu,
-                        const int32_t *sentlens, int L, hipStream_t stream, const float *pad_bias, int rows4 = 0,
-                        const LinearArgs *at_heads = nullptr, const X3Batch *batch = nullptr);
 int launch_linear(const char *tag, const float *X, long ldx, const float *W, long ldw, const float *bias, float *Y, long ldy, int M,
                   int N, int K, int relu, const int32_t *sentlens, int L, hipStream_t stream, const float *pad_bias = nullptr, int nbatch = 1,
                   long bsx = 0, long bsw = 0, long bsy = 0);
@@ -584,43 +577,16 @@ using namespace phonlp;
 
 extern "C" int phonlp_kp(int H) { return kp_of(H); }
 
-// workspace of the engine-2 stage A: split images of the S scorers' X1 [S][M] and bilinear weights [S*KP]
-static size_t arc_x3_ws_bytes(size_t M, int KP, int S) {
-    const size_t K16 = (size_t)(KP + 15) / 16 * 16;
-    return align_up(S * M * 4 * K16, 256) + align_up(S * M * sizeof(float), 256) + align_up((size_t)S * KP * 4 * K16, 256) +
-           align_up((size_t)S * KP * sizeof(float), 256);
-}
-
 // stage A of the 1 or 3 arc scorers + the arc kernel, from the scorers' features XF [M, S*2*KP]
-static int arc_from_features(const float *XF, float *T, void *x3ws, int B, int L, int KP, int S, int use_lin, int use_dist,
+static int arc_from_features(const float *XF, float *T, int B, int L, int KP, int S, int use_lin, int use_dist,
                              const float *Wbt, float *arc_logp, float *raw_opt, hipStream_t st) {
     const int M = B * L;
     int rc;
-    // PHONLP_ARC_X3=1 (A/B switch, off by default): stage A on engine 2.  Measured at B=256, L=128: the GEMM itself
-    // takes 0.156 ms instead of 0.201, but the two split passes it needs (0.04 ms + two launch gaps) cost more than
-    // that: 3.63 vs 3.59 ms per step.
-    static const bool x3_on = getenv("PHONLP_ARC_X3") && atoi(getenv("PHONLP_ARC_X3")) == 1;
-    if (gemm_engine() == 2 && M >= 1024 && x3_on) {
-        // X1 of the S scorers and their bilinear weights are split (one batched pass each), then ONE batched launch
-        // of the f16x3 kernel (item s: X1 of scorer s, its bilinear weight, its slice of T)
-        const int K16 = (KP + 15) / 16 * 16;
-        char *p = (char *)x3ws;
-        void *xp = p;              p += align_up((size_t)S * M * 4 * K16, 256);
-        float *xi = (float *)p;    p += align_up((size_t)S * M * sizeof(float), 256);
-        void *wp = p;              p += align_up((size_t)S * KP * 4 * K16, 256);
-        float *wi = (float *)p;
-        rc = launch_split_rows(XF, (long)S * 2 * KP, M, KP, xp, 0, xi, st, S, 2L * KP);
-        if (rc) return rc;
-        rc = launch_split_rows(Wbt, KP, S * KP, KP, wp, 0, wi, st, 1, 0);
-        if (rc) return rc;
-        const X3Batch bt{S, (long)M * 4 * K16, (long)KP * 4 * K16, KP, M, KP};
-        rc = launch_linear_f16x3("linear:arc_stage_a", xp, 4L * K16, xi, wp, 4L * K16, wi, nullptr, T, (long)S * KP, M, KP, K16,
-                                 0, nullptr, 0, st, nullptr, 0, nullptr, &bt);
-    } else {
-        // stage A of the S scorers as ONE batched launch (item s: X1 of scorer s, its bilinear weight, its slice of T)
-        rc = launch_linear("linear:arc_stage_a", XF, (long)S * 2 * KP, Wbt, KP, nullptr, T, (long)S * KP, M, KP, KP, 0, nullptr, 0,
-                           st, nullptr, S, 2L * KP, (long)KP * KP, KP);
-    }
+    // stage A of the S scorers as ONE batched launch (item s: X1 of scorer s, its bilinear weight, its slice of T).
+    // Engine 1 under engine 2 as well: running it on the f16x3 kernel was measured (the GEMM 0.20 -> 0.16 ms at B=256,
+    // L=128) and dropped, because the two split passes it needs cost more than that (3.63 vs 3.59 ms per step).
+    rc = launch_linear("linear:arc_stage_a", XF, (long)S * 2 * KP, Wbt, KP, nullptr, T, (long)S * KP, M, KP, KP, 0, nullptr, 0,
+                       st, nullptr, S, 2L * KP, (long)KP * KP, KP);
     if (rc) return rc;
     ArcArgs a{T, XF, arc_logp, raw_opt, (long)S * KP, (long)S * 2 * KP, B, L, KP, S, 0, use_lin, use_dist};
     a.LP = (L + 31) / 32 * 32 + 1;
@@ -653,8 +619,7 @@ static int arc_from_features(const float *XF, float *T, void *x3ws, int B, int L
 
 extern "C" size_t phonlp_biaffine_arc_ws_bytes(int B, int L, int H, int n_scorers) {
     const size_t M = (size_t)B * L, KP = kp_of(H);
-    return align_up(M * n_scorers * 2 * KP * sizeof(float), 256) + align_up(M * n_scorers * KP * sizeof(float), 256) +
-           arc_x3_ws_bytes(M, (int)KP, n_scorers);
+    return align_up(M * n_scorers * 2 * KP * sizeof(float), 256) + align_up(M * n_scorers * KP * sizeof(float), 256);
 }
 
 extern "C" int phonlp_deep_biaffine_arc(const float *hidden, int D, int B, int L, int H, int n_scorers, int use_lin,
@@ -679,14 +644,12 @@ extern "C" int phonlp_deep_biaffine_arc(const float *hidden, int D, int B, int L
                            pad_sentlens ? L : 0, st, b12_pad);
     if (rc) return rc;
     if (rc) return rc;
-    void *x3ws = (char *)T + align_up((size_t)M * S * KP * sizeof(float), 256);
-    return arc_from_features(XF, T, x3ws, B, L, KP, S, use_lin, use_dist, Wbt, arc_logp, raw_opt, st);
+    return arc_from_features(XF, T, B, L, KP, S, use_lin, use_dist, Wbt, arc_logp, raw_opt, st);
 }
 
 /* Arc scores from the scorers' first-layer features (engine 2 computes those with phonlp_linear_split). */
 extern "C" size_t phonlp_biaffine_arc_scores_ws_bytes(int B, int L, int H, int n_scorers) {
-    return align_up((size_t)B * L * n_scorers * kp_of(H) * sizeof(float), 256) +
-           arc_x3_ws_bytes((size_t)B * L, kp_of(H), n_scorers);
+    return align_up((size_t)B * L * n_scorers * kp_of(H) * sizeof(float), 256);
 }
 
 extern "C" int phonlp_biaffine_arc_scores(const float *XF, int B, int L, int H, int n_scorers, int use_lin, int use_dist,
@@ -700,8 +663,7 @@ extern "C" int phonlp_biaffine_arc_scores(const float *XF, int B, int L, int H, 
     if (((uintptr_t)XF & 15)) return fail(PHONLP_ERR_SHAPE, "biaffine_arc_scores: XF must be 16-byte aligned");
     if (ws_bytes < phonlp_biaffine_arc_scores_ws_bytes(B, L, H, n_scorers) || !ws)
         return fail(PHONLP_ERR_WORKSPACE, "biaffine_arc_scores: workspace too small");
-    void *x3ws = (char *)ws + align_up((size_t)B * L * n_scorers * kp_of(H) * sizeof(float), 256);
-    return arc_from_features(XF, (float *)ws, x3ws, B, L, kp_of(H), n_scorers, use_lin, use_dist, Wbt, arc_logp, raw_opt,
+    return arc_from_features(XF, (float *)ws, B, L, kp_of(H), n_scorers, use_lin, use_dist, Wbt, arc_logp, raw_opt,
                              as_stream(stream));
 }
 

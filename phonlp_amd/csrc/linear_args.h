@@ -27,17 +27,8 @@ struct LinearArgs {
     float *P;              // mode 2: [N/32][M]
     long ldx2;
     int kpc, kpx;          // mode 2: columns per relation (multiple of 32) and how many of them are real
-    long bsx, bsw, bsy;  // batched launch (gridDim.y > 1): float strides of X, W, Y between the items (linear_f16x3.hip:
-                         // bsx / bsw are BYTE strides of the split images)
-    long bs_rs, bs_cs;   // linear_f16x3.hip, batched launch: strides of row_scale / col_scale between the items
+    long bsx, bsw, bsy;  // batched launch (gridDim.y > 1): float strides of X, W, Y between the items
     int dbg;  // timing-only ablations (PHONLP_X3_ABLATION): 1 = epilogue without its global stores, 2 = no epilogue
-};
-
-// Batched launch of the engine-2 kernel (linear_f16x3.hip): n items, strides between them (images in bytes, Y and the
-// scale vectors in floats)
-struct X3Batch {
-    int n;
-    long bsx, bsw, bsy, bs_rs, bs_cs;
 };
 
 // Epilogue shared by the dense-layer kernels: the wave's accumulators are transposed through a per-wave LDS

@@ -34,15 +34,11 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // ------------------------------------------------------------------------------------------ split
 // One wavefront per row.  K % 4 == 0, X 16-byte aligned, ldx % 4 == 0.
 // `pitch` = bytes between image rows (>= 4*K16: the image may be the leading columns of a wider one).
-// gridDim.y > 1: item y reads X + y*bx (floats) and writes planes + y*rows*pitch, inv_scale + y*rows.
 __global__ __launch_bounds__(256) void split_rows_kernel(const float *X, long ldx, int rows, int K, int K16,
-                                                          unsigned char *planes, long pitch, float *inv_scale, long bx) {
+                                                          unsigned char *planes, long pitch, float *inv_scale) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    X += blockIdx.y * bx;
-    planes += (long)blockIdx.y * rows * pitch;
-    inv_scale += (long)blockIdx.y * rows;
     const float *x = X + (long)row * ldx;
     unsigned mx = 0;
     for (int c = lane * 4; c < K; c += 256) {
@@ -530,14 +526,6 @@ __global__ __launch_bounds__(256, 2) void linear_f16x3_dma_np_kernel(LinearArgs 
     const int wm = wave / WN, wn = wave % WN;
     const int ntiles = a.num_m * a.num_n;
     const int nst = a.K >> 4;
-    if (gridDim.y > 1) {  // batched launch (launch_linear_f16x3 with an X3Batch): item blockIdx.y
-        const long y = blockIdx.y;
-        a.X = reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(a.X) + y * a.bsx);
-        a.W = reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(a.W) + y * a.bsw);
-        a.Y += y * a.bsy;
-        a.row_scale += y * a.bs_rs;
-        a.col_scale += y * a.bs_cs;
-    }
     int m0, n0;
     {
         const int xg = blockIdx.x & 7, jl = blockIdx.x >> 3;
@@ -650,7 +638,7 @@ __global__ __launch_bounds__(256, 2) void linear_f16x3_dma_np_kernel(LinearArgs 
 int launch_linear_f16x3(const char *tag, const void *Xp, long pitch_x, const float *x_inv, const void *Wp, long pitch_w,
                         const float *w_inv, const float *bias, float *Y, long ldy, int M, int N, int K16, int relu,
                         const int32_t *sentlens, int L, hipStream_t stream, const float *pad_bias, int rows4 = 0,
-                        const LinearArgs *at_heads = nullptr, const X3Batch *batch = nullptr) {
+                        const LinearArgs *at_heads = nullptr) {
     if (!Xp || !Wp || !x_inv || !w_inv || (!Y && !at_heads) || M <= 0 || N <= 0 || K16 <= 0)
         return fail(PHONLP_ERR_SHAPE, "linear_split: bad argument");
     if ((K16 & 15) || (pitch_x & 15) || (pitch_w & 15) || pitch_x < 4L * K16 || pitch_w < 4L * K16 ||
@@ -682,14 +670,9 @@ int launch_linear_f16x3(const char *tag, const void *Xp, long pitch_x, const flo
     }
     if (rows4 == 1 && (sentlens || relu || ((uintptr_t)Y & 15)))
         return fail(PHONLP_ERR_SHAPE, "linear_split: the rows-by-4 output takes no activation / padding mask");
-    if (batch) {  // the fragment-at-stage kernel takes batched launches; the others do not
-        if (batch->n < 1 || (batch->bsx & 15) || (batch->bsw & 15) || rows4 || at_heads)
-            return fail(PHONLP_ERR_SHAPE, "linear_split: bad batch");
-        a.bsx = batch->bsx; a.bsw = batch->bsw; a.bsy = batch->bsy; a.bs_rs = batch->bs_rs; a.bs_cs = batch->bs_cs;
-    }
     ProfScope ps(tag, stream);
-    const dim3 g(a.num_m * a.num_n, batch ? batch->n : 1);
-    if (reg_staged && !batch) {
+    const dim3 g(a.num_m * a.num_n);
+    if (reg_staged) {
         if (stage_a) hipLaunchKernelGGL((linear_f16x3_kernel<1>), g, dim3(256), LDS, stream, a);
         else hipLaunchKernelGGL((linear_f16x3_kernel<0>), g, dim3(256), LDS, stream, a);
         return check_launch("linear_f16x3_kernel");
@@ -697,7 +680,7 @@ int launch_linear_f16x3(const char *tag, const void *Xp, long pitch_x, const flo
     // measured (tools/f16x3_probe.py, one box): the register-prefetch loop wins on long K (W1/W2, K = 868: 0.456 vs
     // 0.482 ms) and loses on short K (stage A, K = 408: 1.65 vs 1.55 ms, its 256 VGPRs cost the epilogue); K16 picks.
     static const int pf_env = getenv("PHONLP_X3_PREFETCH") ? atoi(getenv("PHONLP_X3_PREFETCH")) : -1;
-    const bool prefetch = !batch && (pf_env >= 0 ? pf_env != 0 : K16 >= 512);
+    const bool prefetch = pf_env >= 0 ? pf_env != 0 : K16 >= 512;
     if (!prefetch) {
         static bool np_attr = false;
         if (!np_attr) {
@@ -726,22 +709,21 @@ extern "C" size_t phonlp_split_bytes(int rows, int K) {
 namespace phonlp {
 // Split image of X [rows, K] written with row pitch `pitch` bytes (0 = packed, 4*K16).
 int launch_split_rows(const float *X, long ldx, int rows, int K, void *planes, long pitch, float *inv_scale,
-                      hipStream_t stream, int nbatch, long bx) {
+                      hipStream_t stream) {
     if (!X || !planes || !inv_scale || rows <= 0 || K <= 0) return fail(PHONLP_ERR_SHAPE, "split_rows: bad argument");
     const int K16 = (K + 15) / 16 * 16;
     if (pitch == 0) pitch = 4L * K16;
-    if ((K & 3) || (ldx & 3) || ((uintptr_t)X & 15) || ((uintptr_t)planes & 15) || (pitch & 15) || pitch < 4L * K16 ||
-        nbatch < 1 || (bx & 3))
+    if ((K & 3) || (ldx & 3) || ((uintptr_t)X & 15) || ((uintptr_t)planes & 15) || (pitch & 15) || pitch < 4L * K16)
         return fail(PHONLP_ERR_SHAPE, "split_rows: K, ldx must be multiples of 4 and X, planes 16-byte aligned");
     ProfScope ps("split_rows", stream);
-    hipLaunchKernelGGL(split_rows_kernel, dim3(ceil_div(rows, 4), nbatch), dim3(256), 0, stream, X, ldx, rows, K, K16,
-                       reinterpret_cast<unsigned char *>(planes), pitch, inv_scale, bx);
+    hipLaunchKernelGGL(split_rows_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, stream, X, ldx, rows, K, K16,
+                       reinterpret_cast<unsigned char *>(planes), pitch, inv_scale);
     return check_launch("split_rows_kernel");
 }
 }  // namespace phonlp
 
 extern "C" int phonlp_split_rows(const float *X, int ldx, int rows, int K, void *planes, float *inv_scale, void *stream) {
-    return launch_split_rows(X, ldx, rows, K, planes, 0, inv_scale, as_stream(stream), 1, 0);
+    return launch_split_rows(X, ldx, rows, K, planes, 0, inv_scale, as_stream(stream));
 }
 
 extern "C" int phonlp_linear_split(const void *Xp, const float *x_inv, const void *Wp, const float *w_inv,
