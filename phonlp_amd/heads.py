@@ -256,7 +256,10 @@ class TaskHeads:
         w = self.w
         main = torch.cuda.current_stream()
         if not hasattr(self, "_side"):
-            self._side = (torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream())
+            # A/B switches: HIP stream priorities of the MST / tagger streams (0 = default, -1 = high)
+            mst_prio = int(os.environ.get("PHONLP_MST_PRIO", "0"))
+            tag_prio = int(os.environ.get("PHONLP_TAG_PRIO", "0"))
+            self._side = (torch.cuda.Stream(priority=tag_prio), torch.cuda.Stream(priority=mst_prio), torch.cuda.Stream())
         s_tag, s_mst, s_fin = self._side
         lens_d = as_sentlens(sentlens_dep, enc_dep.device)
         lens_t = as_sentlens(sentlens_tag, enc_tag.device)
