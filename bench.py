@@ -86,15 +86,26 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    if os.environ.get("PHONLP_BENCH_DEBUG"):  # where is every rank after N seconds? (hang diagnosis)
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["PHONLP_BENCH_DEBUG"]), exit=True)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # PHONLP_BENCH_REHEARSAL=1: rehearse the multi-rank code path on a one-GPU box (every rank on cuda:0, gloo instead
+    # of RCCL, which refuses two ranks on one device); never used for reported numbers
+    rehearsal = os.environ.get("PHONLP_BENCH_REHEARSAL", "0") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     from phonlp_amd import HeadWeights, TaskHeads
     from phonlp_amd import synthetic as S
@@ -134,6 +145,16 @@ def main():
             ops.eval_counts_into(counts, out["pos"], out["ner"], out["heads"], out["rels"], gold_pos, gold_ner,
                                  gold_head, gold_rel, lt, ld, out["mst_status"])
         return out
+
+    def all_reduce(t, op=None):
+        """RCCL all-reduce of a device tensor (in place); the rehearsal mode's gloo group reduces a host copy."""
+        kw = {} if op is None else {"op": op}
+        if rehearsal:
+            h = t.cpu()
+            dist.all_reduce(h, **kw)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, **kw)
 
     def fence():
         torch.cuda.synchronize()
@@ -175,16 +196,17 @@ def main():
     torch.cuda.current_stream().wait_stream(out_last["tag_stream"])
     counts_all = torch.cat([counts, counts_ent])
     if dist is not None:
-        dist.all_reduce(counts_all)  # the only collective: eval counts over RCCL
+        all_reduce(counts_all)  # the only collective: eval counts over RCCL
     fence()
     elapsed = time.perf_counter() - t0
     kt.__exit__(None, None, None)
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        all_reduce(t, dist.ReduceOp.MAX)
     elapsed = float(t.item())
     kernels_ms = {k: round(v[1], 4) for k, v in sorted(kt.stats.items())}
-    if rank == 0 and not time_all:  # the other kernels' durations: an extra, untimed pass with every launch bracketed
+    if not time_all:  # the other kernels' durations: an extra, untimed pass with every launch bracketed (all ranks run
+        # it, so that they reach the final barrier together; rank 0 reports its own)
         with KernelTimer(max_samples=64 * 4) as kt_all:
             for _ in range(4):
                 step()
@@ -220,7 +242,8 @@ def main():
             "metric": "sentences/sec through POS+NER+dep heads at B=256,L=128",
             "value": sent / elapsed, "unit": "sentences/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU, gloo)" if rehearsal else ""),
             "gemm_engine": eng_name[engine],
             "other_engine_ms_per_step": {short[k]: v for k, v in other_ms.items()} if other_ms else None,
             "config": {"workload": "BASELINE config 3: synthetic B=256 L=128 full heads incl. Chu-Liu-Edmonds MST "
@@ -249,6 +272,7 @@ def main():
             res["speedup_vs_cpu_baseline"] = res["value"] / res["cpu_baseline"]["value"]
         print(json.dumps(res), flush=True)
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 
