@@ -3,7 +3,6 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from phonlp_amd import HeadWeights, TaskHeads, ops, synthetic as S
-from oracle import c_oracle as C
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 dev = torch.device("cuda:0")
 B, L = 256, 128
@@ -18,6 +17,5 @@ for _ in range(reps):
     h, st = ops.mst_one_root(arc, lens)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / reps
-wh, ws = C.mst_batch(arc.cpu().numpy(), [L] * B)
-ok = np.array_equal(h.cpu().numpy(), wh) and not st.any().item()
-print(f"mst B={B} L={L}: {dt*1e3:.3f} ms  parity={'OK' if ok else 'MISMATCH'}", flush=True)
+# timing only: parity of the decoder is the tests' job (tests/test_gpu_parity.py::test_mst_*), tools never touch oracle/
+print(f"mst B={B} L={L}: {dt*1e3:.3f} ms  failures={int(st.ne(0).sum())}", flush=True)
