@@ -205,16 +205,37 @@ __global__ __launch_bounds__(256) void mst_wave_kernel(MstArgs a, int stack_cap)
         }
         if (!skip) {
         // ---- whole workgroup: load + edit the matrix (ref :136, :143-149, :55-57), level-0 arg-max (ref :58)
-        for (int idx = tid; idx < l * l; idx += 256) {
-            const int i = idx / l, j = idx - i * l;
-            double v = (double)arc[(long)i * L + j];
-            if (root >= 1) {
-                if (j == 0 && i >= 1) v = NEG_INF_D;
-                if (i == root) v = j == 0 ? 0.0 : NEG_INF_D;
+        // a wave per row, lanes over columns (no index division); eight rows' loads are issued together so that the
+        // latency of the arc matrix (HBM / L2) is paid once per batch, not once per row
+        for (int i0 = wave; i0 < l; i0 += 32) {
+            float vals[8][NPL];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int i = i0 + 4 * r;
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) {
+                    const int j = lane + 64 * q;
+                    vals[r][q] = (i < l && j < l) ? arc[(long)i * L + j] : 0.f;
+                }
             }
-            if (i == j) v = NEG_INF_D;
-            if (i == 0) v = j == 0 ? 0.0 : NEG_INF_D;
-            SM(i, j) = v;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int i = i0 + 4 * r;
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) {
+                    const int j = lane + 64 * q;
+                    if (i < l && j < l) {
+                        double v = (double)vals[r][q];
+                        if (root >= 1) {
+                            if (j == 0 && i >= 1) v = NEG_INF_D;
+                            if (i == root) v = j == 0 ? 0.0 : NEG_INF_D;
+                        }
+                        if (i == j) v = NEG_INF_D;
+                        if (i == 0) v = j == 0 ? 0.0 : NEG_INF_D;
+                        SM(i, j) = v;
+                    }
+                }
+            }
         }
         for (int t = tid; t < l; t += 256) node[t] = t;
         __syncthreads();
