@@ -132,6 +132,8 @@ def main():
     tag_kind, tag_type = (t.to(dev) for t in tag_tables(ner_vocab))
 
     STREAMING = int(os.environ.get("PHONLP_BENCH_STREAMING", "0"))
+    COUNTS_INLINE = os.environ.get("PHONLP_BENCH_COUNTS_INLINE", "0") == "1"
+    s_cnt = torch.cuda.Stream()
 
     def step():
         # PHONLP_BENCH_STREAMING=1 selects the streaming form: the batch's tail (labels at heads, eval counts) runs on the finishing stream, so the next
@@ -141,9 +143,19 @@ def main():
         # the tagger's stream behind the Viterbi instead of at the tail of the batch
         with torch.cuda.stream(out["tag_stream"]):
             ops.ner_entity_counts_into(counts_ent, out["ner"], gold_ner, lt, tag_kind, tag_type)
-        with torch.cuda.stream(out["stream"]):
-            ops.eval_counts_into(counts, out["pos"], out["ner"], out["heads"], out["rels"], gold_pos, gold_ner,
-                                 gold_head, gold_rel, lt, ld, out["mst_status"])
+        # the tally of this batch runs on a stream of its own behind the batch's last kernel, so that the next batch's
+        # first kernels do not queue behind it (PHONLP_BENCH_COUNTS_INLINE=1: on the batch's finishing stream, A/B)
+        if COUNTS_INLINE:
+            with torch.cuda.stream(out["stream"]):
+                ops.eval_counts_into(counts, out["pos"], out["ner"], out["heads"], out["rels"], gold_pos, gold_ner,
+                                     gold_head, gold_rel, lt, ld, out["mst_status"])
+        else:
+            s_cnt.wait_event(out["done"])
+            with torch.cuda.stream(s_cnt):
+                for k in ("pos", "ner", "heads", "rels", "mst_status"):
+                    out[k].record_stream(s_cnt)
+                ops.eval_counts_into(counts, out["pos"], out["ner"], out["heads"], out["rels"], gold_pos, gold_ner,
+                                     gold_head, gold_rel, lt, ld, out["mst_status"])
         return out
 
     def all_reduce(t, op=None):
@@ -194,6 +206,7 @@ def main():
         out_last = step()
     torch.cuda.current_stream().wait_stream(out_last["stream"])
     torch.cuda.current_stream().wait_stream(out_last["tag_stream"])
+    torch.cuda.current_stream().wait_stream(s_cnt)
     counts_all = torch.cat([counts, counts_ent])
     if dist is not None:
         all_reduce(counts_all)  # the only collective: eval counts over RCCL
