@@ -186,17 +186,20 @@ __device__ __forceinline__ void arc_fold(const ArcArgs &a, int s, int b, int i, 
 // accumulator tiles; after a scorer's last slab its term is added to the LDS row buffer (each lane owns its cells, so
 // no barrier is needed between the terms).  A slab of X2 serves 128 dependents instead of 32: 4x less re-reading of
 // the head-side features and 8x more MFMA work per wave and barrier.
-template <int ENG>
+// ROWS = 128 or 64 dependents per block: 64 halves the LDS footprint (77 KB: two blocks per CU, so one block's slab
+// loads and barriers hide behind the other's MFMAs) at the price of reading the head-side slabs twice as often.
+template <int ENG, int ROWS>
 __global__ __launch_bounds__(256) void arc_kernel128(ArcArgs a) {
+    constexpr int TMW = ROWS / 64;  // 32-row accumulator tiles per wave
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *As = smem;
-    float *Bs = smem + 128 * PITCH;
-    float *rowbuf = smem + 256 * PITCH + 4 * 32 * 33;
+    float *Bs = smem + ROWS * PITCH;
+    float *rowbuf = smem + (ROWS + 128) * PITCH + 4 * 32 * 33;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    float *patch = smem + 256 * PITCH + wave * 32 * 33;
-    const int b = blockIdx.y, i0 = blockIdx.x * 128;
+    float *patch = smem + (ROWS + 128) * PITCH + wave * 32 * 33;
+    const int b = blockIdx.y, i0 = blockIdx.x * ROWS;
     const int L = a.L, KP = a.KP, LP = a.LP;
     const int iv = L - i0;
     const int nk = (KP + BK - 1) / BK;
@@ -207,15 +210,16 @@ __global__ __launch_bounds__(256) void arc_kernel128(ArcArgs a) {
     for (int j0 = 0; j0 < L; j0 += 128) {
         const int jv = L - j0;
         const float *Xb = a.XF + ((long)b * L + j0) * a.ldx;
-        f32x16 acc[2][2];
+        f32x16 acc[TMW][2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TMW; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-        Slab<128, 256> ra, rb;
+        Slab<ROWS, 256> ra;
+        Slab<128, 256> rb;
         slab_load(ra, Tb, a.ldT, iv, 0, KP, tid);
         slab_load(rb, Xb + KP, a.ldx, jv, 0, KP, tid);
         __syncthreads();  // previous column group done with the staging buffers
@@ -229,8 +233,8 @@ __global__ __launch_bounds__(256) void arc_kernel128(ArcArgs a) {
                 slab_load(ra, Tb + s2 * KP, a.ldT, iv, k2, KP, tid);
                 slab_load(rb, Xb + (2 * s2 + 1) * KP, a.ldx, jv, k2, KP, tid);
             }
-            const float *Aw = As + wm * 64 * PITCH, *Bw = Bs + wn * 64 * PITCH;
-            mma_slab<2, 2, ENG>(Aw, Bw, lane, acc, slab_depth(kk * BK, KP));
+            const float *Aw = As + wm * (ROWS / 2) * PITCH, *Bw = Bs + wn * 64 * PITCH;
+            mma_slab<TMW, 2, ENG>(Aw, Bw, lane, acc, slab_depth(kk * BK, KP));
             __syncthreads();
             if (it + 1 < total) {
                 slab_store(ra, As, tid);
@@ -241,7 +245,7 @@ __global__ __launch_bounds__(256) void arc_kernel128(ArcArgs a) {
                 // accumulator tile -> this wave's LDS patch (static offsets), then a rolled loop over the patch: the
                 // unrolled form hoists 64 cell / raw addresses out of the slab loop and spills.
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < TMW; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
 #pragma unroll
@@ -254,7 +258,7 @@ __global__ __launch_bounds__(256) void arc_kernel128(ArcArgs a) {
 #pragma unroll 2
                         for (int e = 0; e < 16; ++e) {
                             const int pr = 2 * e + (lane >> 5);
-                            const int row = wm * 64 + i * 32 + pr;
+                            const int row = wm * (ROWS / 2) + i * 32 + pr;
                             if (row < iv && col < L)
                                 arc_fold(a, s, b, i0 + row, col, patch[pr * 33 + (lane & 31)], plane, rowbuf + row * LP + col);
                         }
@@ -266,7 +270,7 @@ __global__ __launch_bounds__(256) void arc_kernel128(ArcArgs a) {
         }
     }
     __syncthreads();
-    for (int row = wave; row < iv && row < 128; row += 4)
+    for (int row = wave; row < iv && row < ROWS; row += 4)
         arc_softmax_row(rowbuf + row * LP, a.out + ((long)b * L + i0 + row) * L, L, lane);
 }
 
@@ -593,23 +597,28 @@ static int arc_from_features(const float *XF, float *T, int B, int L, int KP, in
     const size_t lds = (size_t)(160 * PITCH + 32 * a.LP) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)arc_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
-                hipSuccess ||
-            hipFuncSetAttribute((const void *)arc_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
-                hipSuccess ||
-            hipFuncSetAttribute((const void *)arc_kernel128<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
-                hipSuccess ||
-            hipFuncSetAttribute((const void *)arc_kernel128<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
-                hipSuccess)
-            return fail(PHONLP_ERR_LAUNCH, "deep_biaffine_arc: cannot raise the dynamic LDS limit");
+        const void *fns[] = {(const void *)arc_kernel<0>, (const void *)arc_kernel<1>, (const void *)arc_kernel128<0, 128>,
+                             (const void *)arc_kernel128<1, 128>, (const void *)arc_kernel128<0, 64>,
+                             (const void *)arc_kernel128<1, 64>};
+        for (const void *f : fns)
+            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                return fail(PHONLP_ERR_LAUNCH, "deep_biaffine_arc: cannot raise the dynamic LDS limit");
         attr_set = true;
     }
     ProfScope ps("arc_stage_b", st);
     static const bool rows32 = getenv("PHONLP_ARC_ROWS32") != nullptr;  // A/B switch
+    // 64 dependents per block (two blocks per CU) or 128 (one): PHONLP_ARC_ROWS, default 64
+    static const int rows = getenv("PHONLP_ARC_ROWS") ? atoi(getenv("PHONLP_ARC_ROWS")) : 64;
     if (L <= 192 && !rows32) {
+        if (rows == 64) {
+            const size_t lds64 = (size_t)(192 * PITCH + 4 * 32 * 33 + 64 * a.LP) * sizeof(float);
+            if (gemm_engine()) hipLaunchKernelGGL((arc_kernel128<1, 64>), dim3(ceil_div(L, 64), B), dim3(256), lds64, st, a);
+            else hipLaunchKernelGGL((arc_kernel128<0, 64>), dim3(ceil_div(L, 64), B), dim3(256), lds64, st, a);
+            return check_launch("arc_kernel128");
+        }
         const size_t lds128 = (size_t)(256 * PITCH + 4 * 32 * 33 + 128 * a.LP) * sizeof(float);
-        if (gemm_engine()) hipLaunchKernelGGL(arc_kernel128<1>, dim3(ceil_div(L, 128), B), dim3(256), lds128, st, a);
-        else hipLaunchKernelGGL(arc_kernel128<0>, dim3(ceil_div(L, 128), B), dim3(256), lds128, st, a);
+        if (gemm_engine()) hipLaunchKernelGGL((arc_kernel128<1, 128>), dim3(ceil_div(L, 128), B), dim3(256), lds128, st, a);
+        else hipLaunchKernelGGL((arc_kernel128<0, 128>), dim3(ceil_div(L, 128), B), dim3(256), lds128, st, a);
         return check_launch("arc_kernel128");
     }
     if (gemm_engine()) hipLaunchKernelGGL(arc_kernel<1>, dim3(ceil_div(L, 32), B), dim3(256), lds, st, a);
