@@ -450,6 +450,32 @@ def test_tiny_and_ragged_batches_end_to_end(dev, engine, B, L, lens1):
         assert (out["ner"][b, lens[b]:] == 0).all() and (out["pos"][b, lens[b]:] == 0).all()
 
 
+@pytest.mark.parametrize("lin,dist", [(False, False), (True, False), (False, True)])
+def test_scorer_flags(dev, engine, lin, dist):
+    """args["linearization"] / args["distance"] off (ref annotate_model.py:77-94, 192-208): arc scores against the
+    oracle with the same flags, through parser() (layer by layer) and annotate_batch (folded weights, engine paths)."""
+    from phonlp_amd import HeadWeights, TaskHeads
+    from phonlp_amd import synthetic as S
+    B, L = 12, 40
+    sd = S.make_state_dict(64, 12, 48, 7, 6, 5, seed=11)
+    enc_dep, enc_tag = S.make_encoder_outputs(B, L, 64, seed=5)
+    lens1 = S.make_sentlens(B, L, True)
+    lens = [l - 1 for l in lens1]
+    heads = TaskHeads(HeadWeights.from_state_dict(sd, dev, linearization=lin, distance=dist))
+    dep = heads.parser(enc_dep.to(dev), lens1)
+    od = O.dep_heads(enc_dep, lens1, sd, linearization=lin, distance=dist)
+    _close(dep["arc_logp"], od["arc_logp"], rtol=1e-3, atol=1e-4)
+    out = heads.annotate_batch(enc_dep.to(dev), lens1, enc_tag.to(dev), lens)
+    wh, ws = C.mst_batch(od["arc_logp"].numpy(), lens1)
+    assert not ws.any() and (out["mst_status"] == 0).all()
+    assert np.array_equal(out["heads"].cpu().numpy(), wh)
+    rel = np.zeros((B, L), np.int64)
+    for b in range(B):
+        for i in range(1, lens1[b]):
+            rel[b, i] = int(od["label_argmax"][b, i, wh[b, i]])
+    assert np.array_equal(out["rels"].cpu().numpy(), rel)
+
+
 def test_headline_batch_properties(dev, engine):
     """B=256, L=128 (BASELINE config 3): sentences are independent, so any sub-batch must reproduce the big
     batch bit-for-bit; decoded trees must be single-rooted and acyclic; decoders match the C oracle."""
