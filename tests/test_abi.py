@@ -47,6 +47,17 @@ def test_argument_errors_without_gpu(heads_lib):
     one = ctypes.c_void_p(16)
     assert heads_lib.phonlp_crf_viterbi(one, one, one, 1, 4, 65, one, None, None) == -4  # T > 64 unsupported
     assert heads_lib.phonlp_linear(one, 6, one, 6, None, one, 4, 2, 2, 6, 0, None, 0, None) == -1  # K % 4 != 0
+    # fused tagger head: NULL operands, more than 64 POS tags (one lane per tag), workspace too small
+    assert heads_lib.phonlp_tagger_head(None, 768, None, 1, 1, 768, None, None, None, None, None, None, None, 400, 24, 100, 9,
+                                        None, None, None, None, 0, None) == -1
+    assert b"tagger_head" in heads_lib.phonlp_last_error()
+    args = [one, 768, one, 2, 8, 768, one, one, one, one, one, one, one, 400, 24, 100, 9, one, one, None]
+    assert heads_lib.phonlp_tagger_head(*args[:14], 65, *args[15:], one, 1 << 30, None) == -4
+    assert heads_lib.phonlp_tagger_head(*args, one, 16, None) == -2
+    assert heads_lib.phonlp_tagger_head_ws_bytes(2, 8, 768, 400, 24, 100, 9) > 16 * (412 + 24) * 4
+    # engine-2 stage A refuses what the rows-by-4 layout cannot take before any launch
+    assert heads_lib.phonlp_label_stage_a_split(None, None, None, None, None, 1, 1, 400, 33, None, None) == -1
+    assert heads_lib.phonlp_profile_only(b"linear:label_stage_a") == 0 and heads_lib.phonlp_profile_only(None) == 0
     assert heads_lib.phonlp_mst_ws_bytes(256, 128) > 0
     assert heads_lib.phonlp_biaffine_label_ws_bytes(256, 128, 400, 33) == 256 * 128 * (2 * 408 + 33 * 408) * 4
 
