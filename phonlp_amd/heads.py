@@ -263,8 +263,6 @@ class TaskHeads:
         s_tag, s_mst, s_fin = self._side
         lens_d = as_sentlens(sentlens_dep, enc_dep.device)
         lens_t = as_sentlens(sentlens_tag, enc_tag.device)
-        start = torch.cuda.Event()
-        start.record(main)
         # tagger chain on its own stream
         def run_tagger(after):
             s_tag.wait_event(after)
@@ -288,6 +286,8 @@ class TaskHeads:
         tagger_later = split and os.environ.get("PHONLP_TAGGER_LATE", "1") == "2"
         tagger_late = tagger_late or os.environ.get("PHONLP_TAGGER_LATE", "1") == "2"
         if not tagger_late and not tagger_later:
+            start = torch.cuda.Event()
+            start.record(main)
             tag, ner, tag_done = run_tagger(start)
         # parser chain up to the arc log-probs on the main stream
         B, Ld, D = enc_dep.shape[0], enc_dep.shape[1], enc_dep.shape[2] + w.emb_dep.shape[1]
