@@ -28,7 +28,18 @@ struct MstArgs {
     double *cand_score;    // [B][L]
     uint32_t *cand_tree;   // [B][L][Lw] candidate trees, one byte per node, Lw = ceil(L/4) words
     int max_waiters;       // workgroups allowed to wait for late candidates at one time (they hold a CU's LDS)
+    // mst.hip, two-phase form for sentences too long for the wave kernel: mode 0 = everything in one workgroup per
+    // sentence; mode 1 = the unconstrained decode only (a sentence with >= 2 children of ROOT is left PENDING with its
+    // tree in tree0g); mode 2 = grid of B x cslots workgroups, workgroup (b, s) decodes candidates s, s + cslots, ...
+    // of sentence b and leaves its best in cs_*; mst_pick_kernel then takes the first best over the slots.
+    int mode, cslots;
+    uint16_t *tree0g;      // [B][L] unconstrained tree of a PENDING sentence
+    double *cs_score;      // [B][cslots] best score of the slot's candidates (-inf: none finite)
+    int32_t *cs_idx;       // [B][cslots] candidate number of that best (ascending ROOT-child order), -2: decode error
+    uint16_t *cs_tree;     // [B][cslots][L] its tree
 };
+
+#define PHONLP_MST_PENDING 3  // internal: between the phases of the two-phase form
 
 #ifdef MST_STAMPS
 #define STAMP(k)                                              \

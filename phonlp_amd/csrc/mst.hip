@@ -31,16 +31,24 @@ enum { SC_M = 0, SC_NEXT, SC_NROOT, SC_FINITE, SC_NNEED, SC_TAKE, SC_COUNT = 16 
 template <bool IN_LDS>
 __global__ __launch_bounds__(1024) void mst_kernel(MstArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int b = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
+    const int tid = threadIdx.x, NT = blockDim.x;
+    const int mode = a.mode, R = a.cslots;
+    const int wg = blockIdx.x;                      // workspace region of this workgroup
+    const int b = mode == 2 ? wg / R : wg;          // sentence
+    const int slot = mode == 2 ? wg % R : 0;        // mode 2: first candidate this workgroup decodes
     const int lane = tid & 63, wave = tid >> 6, nwaves = NT >> 6;
     const int L = a.L, pitch = a.pitch;
     int l = a.sentlens[b];
     if (l > L) l = L;
     int32_t *hout = a.heads + (long)b * L;
-    for (int t = tid; t < L; t += NT) hout[t] = 0;
-    if (l <= 1) {  // l == 1: ROOT only -- the reference hits its broken assert (no candidate root)
-        if (tid == 0) a.status[b] = l == 1 ? PHONLP_MST_NO_FINITE_TREE : PHONLP_MST_OK;
-        return;
+    if (mode == 2) {  // candidates of a sentence the first phase left pending (block-uniform tests)
+        if (a.status[b] != PHONLP_MST_PENDING || slot >= a.cand_n[b]) return;
+    } else {
+        for (int t = tid; t < L; t += NT) hout[t] = 0;
+        if (l <= 1) {  // l == 1: ROOT only -- the reference hits its broken assert (no candidate root)
+            if (tid == 0) a.status[b] = l == 1 ? PHONLP_MST_NO_FINITE_TREE : PHONLP_MST_OK;
+            return;
+        }
     }
     // ---- carve LDS
     size_t off = 0;
@@ -49,7 +57,7 @@ __global__ __launch_bounds__(1024) void mst_kernel(MstArgs a) {
         S = reinterpret_cast<double *>(smem_raw);
         off = (size_t)L * pitch * sizeof(double);
     } else {
-        S = a.gmat + (long)b * a.gmat_stride;
+        S = a.gmat + (long)wg * a.gmat_stride;
     }
     double *ev = reinterpret_cast<double *>(smem_raw + off); off += (size_t)L * 8;
     double *lv = reinterpret_cast<double *>(smem_raw + off); off += (size_t)L * 8;
@@ -63,7 +71,7 @@ __global__ __launch_bounds__(1024) void mst_kernel(MstArgs a) {
     int *wtot = sc + SC_COUNT;  // 16 entries
 
     const float *arc = a.arc + (long)b * L * L;
-    uint16_t *stack = a.stack + (long)b * a.stack_stride;
+    uint16_t *stack = a.stack + (long)wg * a.stack_stride;
 #define SM(r, c) S[(long)(r) * pitch + (c)]
 #define LSYNC()                     \
     do {                            \
@@ -79,6 +87,24 @@ __global__ __launch_bounds__(1024) void mst_kernel(MstArgs a) {
     double best_score = NEG_INF_D;
     int have_best = 0;
     int err = 0;
+    int ci = -1, best_ci = -1;  // mode 2: number of the current / best candidate (ascending ROOT-child order)
+    // the next child of ROOT in the unconstrained tree after `from` (INT_MAX: none); block-wide, ends on a barrier
+    auto next_candidate = [&](int from) {
+        if (tid == 0) sc[SC_NEXT] = INT_MAX;
+        __syncthreads();
+        if (tid < l && tid > from && tree0[tid] == 0) atomicMin(&sc[SC_NEXT], tid);
+        __syncthreads();
+        const int nx = sc[SC_NEXT];
+        __syncthreads();
+        return nx;
+    };
+    if (mode == 2) {
+        if (tid < l) tree0[tid] = a.tree0g[(long)b * L + tid];
+        __syncthreads();
+        root = 0;
+        for (int s2 = 0; s2 <= slot; ++s2) root = next_candidate(root);  // slot < cand_n: these exist
+        ci = slot;
+    }
 
     for (;;) {
         // -------------------------------------------------------------- load + edit the matrix
@@ -284,6 +310,11 @@ __global__ __launch_bounds__(1024) void mst_kernel(MstArgs a) {
                 if (tid == 0) a.status[b] = PHONLP_MST_OK;
                 return;
             }
+            if (mode == 1 && sc[SC_NROOT] >= 2) {  // the candidates go to the second phase's grid
+                if (tid < l) a.tree0g[(long)b * L + tid] = (uint16_t)cur[tid];
+                if (tid == 0) { a.cand_n[b] = sc[SC_NROOT]; a.status[b] = PHONLP_MST_PENDING; }
+                return;
+            }
         } else {
             // tree_probs = _scores[arange, _tree] on the EDITED top-level matrix (ref :157)
             if (tid == 0) sc[SC_FINITE] = 1;
@@ -308,11 +339,19 @@ __global__ __launch_bounds__(1024) void mst_kernel(MstArgs a) {
             if (score > best_score) {  // strict: the first best candidate wins (ref :159)
                 best_score = score;
                 have_best = 1;
+                best_ci = ci;
                 if (tid < l) besttree[tid] = cur[tid];
             }
-            if (tid == 0) sc[SC_NEXT] = INT_MAX;
-            __syncthreads();
-            if (tid < l && tid > root && tree0[tid] == 0) atomicMin(&sc[SC_NEXT], tid);
+            if (mode == 2) {  // this workgroup's next candidate: R further on
+                int nx = root;
+                for (int s2 = 0; s2 < R && nx != INT_MAX; ++s2) nx = next_candidate(nx);
+                if (tid == 0) sc[SC_NEXT] = nx;
+                ci += R;
+            } else {
+                if (tid == 0) sc[SC_NEXT] = INT_MAX;
+                __syncthreads();
+                if (tid < l && tid > root && tree0[tid] == 0) atomicMin(&sc[SC_NEXT], tid);
+            }
             __syncthreads();
         }
         const int next = sc[SC_NEXT];
@@ -320,6 +359,15 @@ __global__ __launch_bounds__(1024) void mst_kernel(MstArgs a) {
         STAMP(8);
         if (next == INT_MAX) break;
         root = next;
+    }
+    if (mode == 2) {  // this slot's best (or its failure) for mst_pick_kernel
+        const long q = (long)b * R + slot;
+        if (tid < l && have_best && !err) a.cs_tree[q * L + tid] = (uint16_t)besttree[tid];
+        if (tid == 0) {
+            a.cs_score[q] = (have_best && !err) ? best_score : NEG_INF_D;
+            a.cs_idx[q] = err ? -2 : best_ci;
+        }
+        return;
     }
 #ifdef MST_STAMPS
     if (tid == 0 && a.dbg)
@@ -339,6 +387,34 @@ __global__ __launch_bounds__(1024) void mst_kernel(MstArgs a) {
 #undef LSYNC
 }
 
+// Second half of the two-phase form: the winner among a pending sentence's slots -- greatest score, lowest
+// candidate number among equals, which is the reference's strict '>' over the candidates in ascending order (:159).
+__global__ void mst_pick_kernel(MstArgs a) {
+    const int b = blockIdx.x, tid = threadIdx.x, L = a.L, R = a.cslots;
+    if (a.status[b] != PHONLP_MST_PENDING) return;
+    int l = a.sentlens[b];
+    if (l > L) l = L;
+    const int ns = a.cand_n[b] < R ? a.cand_n[b] : R;
+    double best = NEG_INF_D;
+    int bs = -1, bi = INT_MAX, bad = 0;
+    for (int s = 0; s < ns; ++s) {
+        const double sc = a.cs_score[(long)b * R + s];
+        const int ix = a.cs_idx[(long)b * R + s];
+        if (ix == -2) bad = 1;
+        else if (ix >= 0 && (sc > best || (sc == best && ix < bi)) && sc > NEG_INF_D) { best = sc; bs = s; bi = ix; }
+    }
+    if (!bad && bs >= 0)
+        for (int t = tid; t < l; t += blockDim.x) a.heads[(long)b * L + t] = a.cs_tree[((long)b * R + bs) * L + t];
+    if (tid == 0) a.status[b] = bad ? 2 : (bs >= 0 ? PHONLP_MST_OK : PHONLP_MST_NO_FINITE_TREE);
+}
+
+// slots per sentence of the two-phase form (candidates beyond that many share the slots round-robin)
+constexpr int kCandSlots = 4;
+static bool mst_two_phase() {
+    static const bool off = getenv("PHONLP_MST_TWO_PHASE") && atoi(getenv("PHONLP_MST_TWO_PHASE")) == 0;  // A/B switch
+    return !off;
+}
+
 static size_t mst_aux_bytes(int L) { return (size_t)L * 8 * 3 + 32 + (size_t)L * 4 * 17 + (SC_COUNT + 16) * 4; }
 static bool mst_fits_lds(int L) { return (size_t)L * mst_pitch(L) * 8 + mst_aux_bytes(L) <= 160 * 1024; }
 
@@ -346,10 +422,20 @@ static bool mst_fits_lds(int L) { return (size_t)L * mst_pitch(L) * 8 + mst_aux_
 
 using namespace phonlp;
 
+// workgroup regions (expansion stack, global matrix) of a launch: one per sentence, or one per (sentence, slot)
+static size_t mst_regions(int B, int L) { return (!mst_fits_lds(L) && !mst_wave_fits(L)) ? (size_t)B * kCandSlots : (size_t)B; }
+static size_t mst_two_phase_bytes(int B, int L) {
+    const size_t q = (size_t)B * kCandSlots;
+    return align_up((size_t)B * L * sizeof(uint16_t), 256) + align_up((size_t)B * sizeof(int32_t), 256) +
+           align_up(q * sizeof(double), 256) + align_up(q * sizeof(int32_t), 256) + align_up(q * L * sizeof(uint16_t), 256);
+}
+
 extern "C" size_t phonlp_mst_ws_bytes(int B, int L) {
-    size_t bytes = align_up((size_t)B * L * mst_lvl_stride(L) * sizeof(uint16_t), 256);
-    if (!mst_fits_lds(L)) bytes += align_up((size_t)B * L * mst_pitch(L) * sizeof(double), 256);
+    const size_t regions = mst_regions(B, L);
+    size_t bytes = align_up(regions * L * mst_lvl_stride(L) * sizeof(uint16_t), 256);
+    if (!mst_fits_lds(L)) bytes += align_up(regions * L * mst_pitch(L) * sizeof(double), 256);
     if (mst_wave_fits(L)) bytes += mst_share_bytes(B, L);
+    else if (!mst_fits_lds(L)) bytes += mst_two_phase_bytes(B, L);
     return bytes;
 }
 
@@ -381,19 +467,46 @@ extern "C" int phonlp_mst_one_root(const float *arc, const int32_t *sentlens, in
         attr_set = true;
     }
     ProfScope ps("mst", as_stream(stream));
+    const size_t regions = mst_regions(B, L);
+    const size_t stack_bytes = align_up(regions * L * a.lvl_stride * sizeof(uint16_t), 256);
     if (mst_wave_fits(L) && !getenv("PHONLP_MST_BLOCKSYNC")) {
-        size_t off = align_up((size_t)B * L * a.lvl_stride * sizeof(uint16_t), 256);
-        if (!in_lds) off += align_up((size_t)B * L * a.pitch * sizeof(double), 256);
+        size_t off = stack_bytes;
+        if (!in_lds) off += align_up(regions * L * a.pitch * sizeof(double), 256);
         mst_share_carve(a, (char *)ws + off);
         return launch_mst_wave(a, as_stream(stream));
     }
     if (in_lds) {
         lds += (size_t)L * a.pitch * sizeof(double);
         hipLaunchKernelGGL(mst_kernel<true>, dim3(B), dim3(threads), lds, as_stream(stream), a);
-    } else {
-        a.gmat = (double *)((char *)ws + align_up((size_t)B * L * a.lvl_stride * sizeof(uint16_t), 256));
-        a.gmat_stride = (long)L * a.pitch;
-        hipLaunchKernelGGL(mst_kernel<false>, dim3(B), dim3(threads), lds, as_stream(stream), a);
+        return check_launch("mst_kernel");
     }
-    return check_launch("mst_kernel");
+    a.gmat = (double *)((char *)ws + stack_bytes);
+    a.gmat_stride = (long)L * a.pitch;
+    if (mst_wave_fits(L) || !mst_two_phase()) {
+        hipLaunchKernelGGL(mst_kernel<false>, dim3(B), dim3(threads), lds, as_stream(stream), a);
+        return check_launch("mst_kernel");
+    }
+    // Two-phase form: the unconstrained decodes (one workgroup per sentence), then the single-root candidates of the
+    // sentences that need them side by side on a B x kCandSlots grid (the reference decodes them one after the other,
+    // :151-160; so did this kernel, leaving most of the chip idle when B is small), then the pick.
+    {
+        char *p = (char *)ws + stack_bytes + align_up(regions * L * a.pitch * sizeof(double), 256);
+        const size_t q = (size_t)B * kCandSlots;
+        a.tree0g = (uint16_t *)p;   p += align_up((size_t)B * L * sizeof(uint16_t), 256);
+        a.cand_n = (int32_t *)p;    p += align_up((size_t)B * sizeof(int32_t), 256);
+        a.cs_score = (double *)p;   p += align_up(q * sizeof(double), 256);
+        a.cs_idx = (int32_t *)p;    p += align_up(q * sizeof(int32_t), 256);
+        a.cs_tree = (uint16_t *)p;
+    }
+    a.cslots = kCandSlots;
+    a.mode = 1;
+    hipLaunchKernelGGL(mst_kernel<false>, dim3(B), dim3(threads), lds, as_stream(stream), a);
+    int rc = check_launch("mst_kernel");
+    if (rc) return rc;
+    a.mode = 2;
+    hipLaunchKernelGGL(mst_kernel<false>, dim3(B * kCandSlots), dim3(threads), lds, as_stream(stream), a);
+    rc = check_launch("mst_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(mst_pick_kernel, dim3(B), dim3(256), 0, as_stream(stream), a);
+    return check_launch("mst_pick_kernel");
 }

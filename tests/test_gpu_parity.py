@@ -263,7 +263,10 @@ def test_mst_golden_bit_exact(dev, golden):
 
 
 @pytest.mark.parametrize("B,L,kind", [(256, 128, "randn"), (128, 128, "rooty"), (128, 100, "ints"), (64, 128, "pairs"),
-                                      (24, 160, "randn"), (8, 300, "randn"), (6, 512, "randn")])
+                                      (24, 160, "randn"), (8, 300, "randn"), (6, 512, "randn"),
+                                      # the two-phase form of the long-sentence kernel: many candidate roots per sentence
+                                      # (more than its four slots: round-robin), all-ties integer matrices, pair cycles
+                                      (12, 160, "rooty"), (6, 200, "ints"), (9, 170, "pairs")])
 def test_mst_random_vs_c_oracle(dev, B, L, kind):
     rng = np.random.default_rng(B * 3 + L)
     mats = []
