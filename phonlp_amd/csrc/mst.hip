@@ -108,16 +108,28 @@ __global__ __launch_bounds__(1024) void mst_kernel(MstArgs a) {
 
     for (;;) {
         // -------------------------------------------------------------- load + edit the matrix
-        for (int idx = tid; idx < l * l; idx += NT) {
-            const int i = idx / l, j = idx - i * l;
-            double v = (double)arc[(long)i * L + j];
-            if (root >= 1) {
-                if (j == 0 && i >= 1) v = NEG_INF_D;
-                if (i == root) v = j == 0 ? 0.0 : NEG_INF_D;
+        // a wave per row, lanes over columns, eight loads in flight per lane (no index division)
+        for (int i = wave; i < l; i += nwaves) {
+            const float *arow = arc + (long)i * L;
+            for (int j0 = lane; j0 < l; j0 += 64 * 8) {
+                float vals[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) vals[t] = (j0 + 64 * t < l) ? arow[j0 + 64 * t] : 0.f;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const int j = j0 + 64 * t;
+                    if (j < l) {
+                        double v = (double)vals[t];
+                        if (root >= 1) {
+                            if (j == 0 && i >= 1) v = NEG_INF_D;
+                            if (i == root) v = j == 0 ? 0.0 : NEG_INF_D;
+                        }
+                        if (i == j) v = NEG_INF_D;                      // ref :55
+                        if (i == 0) v = j == 0 ? 0.0 : NEG_INF_D;       // ref :56-57
+                        SM(i, j) = v;
+                    }
+                }
             }
-            if (i == j) v = NEG_INF_D;                      // ref :55
-            if (i == 0) v = j == 0 ? 0.0 : NEG_INF_D;       // ref :56-57
-            SM(i, j) = v;
         }
         if (tid < l) { node[tid] = tid; need[tid] = tid; }  // need[]: list of rows whose arg-max must be (re)scanned
         if (tid == 0) sc[SC_NNEED] = l;
@@ -134,10 +146,17 @@ __global__ __launch_bounds__(1024) void mst_kernel(MstArgs a) {
                 const int rs = node[row];
                 double bv = NEG_INF_D;
                 int bi = INT_MAX;
-                if (lane < n) { bv = SM(rs, node[lane]); bi = lane; }
-                for (int c = lane + 64; c < n; c += 64) {
-                    const double v = SM(rs, node[c]);
-                    if (v > bv) { bv = v; bi = c; }
+                // eight columns per lane and trip: their loads (through L2 when the matrix is in global memory) are
+                // in flight together; compared in ascending column order, strict '>': the first maximum
+                for (int c0 = lane; c0 < n; c0 += 64 * 8) {
+                    double v[8];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) v[t] = (c0 + 64 * t < n) ? SM(rs, node[c0 + 64 * t]) : NEG_INF_D;
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        const int c = c0 + 64 * t;
+                        if (c < n && (bi == INT_MAX || v[t] > bv)) { bv = v[t]; bi = c; }
+                    }
                 }
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) {
@@ -153,7 +172,7 @@ __global__ __launch_bounds__(1024) void mst_kernel(MstArgs a) {
             //     mn[v] is the minimum over >= n consecutive nodes, i.e. the whole cycle for cycle nodes
             if (tid < n) { P0[tid] = hdA[tid]; mn0[tid] = tid; flag[tid] = 0; }
             if (tid == 0) { sc[SC_M] = 0; sc[SC_NNEED] = 0; }
-            LSYNC();
+            lds_barrier();  // only LDS arrays are exchanged here
             int *Pc = P0, *Pn = P1, *mc = mn0, *mx = mn1;
             for (int span = 1; span < n; span <<= 1) {
                 if (tid < n) {
@@ -162,14 +181,14 @@ __global__ __launch_bounds__(1024) void mst_kernel(MstArgs a) {
                     const int m1 = mc[tid], m2 = mc[p];
                     mx[tid] = m1 < m2 ? m1 : m2;
                 }
-                LSYNC();
+                lds_barrier();  // only LDS arrays are exchanged here
                 int *t1 = Pc; Pc = Pn; Pn = t1;
                 int *t2 = mc; mc = mx; mx = t2;
             }
             if (tid < n) flag[Pc[tid]] = 1;
-            LSYNC();
+            lds_barrier();  // only LDS arrays are exchanged here
             if (tid < n && flag[tid]) atomicMax(&sc[SC_M], mc[tid]);
-            LSYNC();
+            lds_barrier();  // only LDS arrays are exchanged here
             const int M = sc[SC_M];
             STAMP(2);
             if (M == 0) break;  // only ROOT's self loop is left: hdA is a tree
@@ -179,7 +198,7 @@ __global__ __launch_bounds__(1024) void mst_kernel(MstArgs a) {
             if (tid < n) { f = (flag[tid] && mc[tid] == M) ? 1 : 0; incyc[tid] = f; }
             const unsigned long long bal = __ballot(f);
             if (lane == 0) wtot[wave] = __popcll(bal);
-            LSYNC();
+            lds_barrier();  // only LDS arrays are exchanged here
             int rc = __popcll(bal & ((1ull << lane) - 1ull));
             int c = 0;
             for (int w = 0; w < nwaves; ++w) {
@@ -193,7 +212,7 @@ __global__ __launch_bounds__(1024) void mst_kernel(MstArgs a) {
                 else rest[tid - rc] = tid;
                 rankr[tid] = tid - rc;
             }
-            LSYNC();
+            lds_barrier();  // only LDS arrays are exchanged here
             STAMP(3);
             // (4) cycle edge scores and their numpy-ordered sum (ref :73-75)
             if (tid < c) {
@@ -278,11 +297,9 @@ __global__ __launch_bounds__(1024) void mst_kernel(MstArgs a) {
                 const int sx = cur[tid];
                 oth[r_rest[tid]] = sx < k ? (int)r_rest[sx] : (int)r_cyc[r_lp[tid]];
             }
-            if (tid < c) oth[r_cyc[tid]] = r_hd[r_cyc[tid]];
-            __syncthreads();
-            if (tid == 0) {
+            if (tid < c) {  // cycle members keep their head, except the one the metanode's head enters through
                 const int mh = cur[k];
-                oth[r_cyc[r_ep[mh]]] = r_rest[mh];
+                oth[r_cyc[tid]] = tid == (int)r_ep[mh] ? (int)r_rest[mh] : (int)r_hd[r_cyc[tid]];
             }
             __syncthreads();
             int *t = cur; cur = oth; oth = t;

@@ -7,7 +7,7 @@ from phonlp_amd import _lib
 _lib.LIB_PATH = os.path.join(ROOT, "tools", "libphonlp_heads_stamps.so")
 from phonlp_amd import HeadWeights, TaskHeads, ops, synthetic as S
 dev = torch.device("cuda:0")
-B, L = 256, 128
+B, L = int(os.environ.get("STAMP_B", 256)), int(os.environ.get("STAMP_L", 128))
 heads = TaskHeads(HeadWeights.from_state_dict(S.make_state_dict(), dev))
 enc_dep, _ = S.make_encoder_outputs(B, L)
 lens = torch.tensor([L] * B, dtype=torch.int32, device=dev)
