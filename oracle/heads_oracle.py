@@ -160,6 +160,41 @@ def dep_heads(enc, sentlens, p, linearization=True, distance=True, keep_label_sc
     return out
 
 
+def dep_loss(dep, sentlens, gold_head, gold_rel, number_of_words, linearization=True, distance=True):
+    """ref: models/jointmodel/model.py:209-236 (the eval=False branch of dep_forward), dropout off.
+
+    dep: the dict of ``dep_heads`` (needs unlabeled_raw / lin_raw / dist_raw / label_scores); gold_head, gold_rel:
+    B x (L-1) int64, zeros on padding, heads counted with ROOT = 0.  Returns (total, [arc, label, lin, dist]):
+    total = (arc CE + label CE + lin CE + dist term) / number_of_words, each term a SUM over words.
+    Quirks kept: arc and label cross-entropies skip padded words (target -1, ignore_index) and the arc soft-max
+    runs over the sentence's own columns only (:212); the linearization and distance terms (:225-234) are NOT
+    masked -- padded rows contribute with whatever head the tensor holds there (0 from get_long_tensor)."""
+    unl, lin, dist, lab = dep["unlabeled_raw"], dep["lin_raw"], dep["dist_raw"], dep["label_scores"]
+    B, L, _ = unl.shape
+    arc = arc_epilogue(unl, lin if linearization else None, dist if distance else None)  # :188-207
+    pad = ~_row_mask(sentlens, B, L)  # word_mask: True on padding
+    head = torch.as_tensor(gold_head, dtype=torch.long)
+    rel = torch.as_tensor(gold_rel, dtype=torch.long)
+    ce = lambda x, t: F.cross_entropy(x, t, ignore_index=-1, reduction="sum")  # crit_dep (:93)
+    arc_t = arc[:, 1:, :].masked_fill(pad.unsqueeze(1), NEG_INF)  # :211-212
+    t_arc = ce(arc_t.reshape(-1, L), head.masked_fill(pad[:, 1:], -1).reshape(-1))  # :213-216
+    O = lab.shape[3]
+    lab_h = torch.gather(lab[:, 1:], 2, head.view(B, L - 1, 1, 1).expand(-1, -1, -1, O)).reshape(-1, O)  # :218-221
+    t_lab = ce(lab_h, rel.masked_fill(pad[:, 1:], -1).reshape(-1))  # :222-223
+    off = (torch.arange(L).view(1, 1, L) - torch.arange(L).view(1, L, 1)).expand(B, L, L)
+    t_lin = unl.new_zeros(())
+    if linearization:  # :225-230
+        s = torch.gather(lin[:, 1:], 2, head.unsqueeze(2)).view(-1)
+        two = torch.stack([-s / 2, s / 2], 1)
+        t_lin = ce(two, torch.gather((off[:, 1:] > 0).long(), 2, head.unsqueeze(2)).view(-1))
+    t_dist = unl.new_zeros(())
+    if distance:  # :199-203, :232-234
+        kld = -torch.log((torch.abs(off).float() - (1 + F.softplus(dist))) ** 2 / 2 + 1)
+        t_dist = -torch.gather(kld[:, 1:], 2, head.unsqueeze(2)).sum()
+    total = (t_arc + t_lab + t_lin + t_dist) / number_of_words  # :236
+    return total, [t_arc, t_lab, t_lin, t_dist]
+
+
 # --------------------------------------------------------------------------------------
 # a10: Viterbi
 # --------------------------------------------------------------------------------------

@@ -423,6 +423,67 @@ def gen_trainer():
     save("trainer_small.npz", **arrs)
 
 
+# ---------------------------------------------------------------------------- F9 training-side parser loss
+def gen_dep_loss():
+    """The eval=False branch of the training model's dep_forward (models/jointmodel/model.py:162-236) in .eval() mode
+    (every dropout the identity) on ragged batches with random gold trees: the loss value and the three
+    cross-entropy sums the reference's own `crit_dep` returned on the way (the distance term is the rest)."""
+    import tempfile
+    amodel = build_joint_model(seed=808)
+    from phonlp.models.jointmodel.trainer import JointTrainer
+    with tempfile.TemporaryDirectory() as td:
+        amodel.phobert.save_pretrained(td)
+        args = dict(amodel.args, pretrained_lm=td)
+        trainer = JointTrainer(args=args, vocab=amodel.vocab, config_phobert=amodel.phobert.config, use_cuda=False)
+    missing, unexpected = trainer.model.load_state_dict(amodel.state_dict(), strict=False)
+    assert not unexpected and all(m.startswith("drop_replacement") for m in missing), (missing, unexpected)
+    model = trainer.model.eval()
+    with open(os.path.join(REF, "sample_data", "input.txt")) as f:
+        lines = [ln.strip() for ln in f if ln.strip()]
+    arrs = {f"p_{k}": v for k, v in head_state(amodel).items()}
+    recorded = []
+    crit = model.crit_dep
+
+    class Recording(torch.nn.Module):  # the reference's own criterion, its return values noted on the way
+        def forward(self, x, t):
+            out = crit(x, t)
+            recorded.append(out.item())  # the value now: the caller goes on adding to the first one in place
+            return out
+
+    model.crit_dep = Recording()
+    captured = []
+    orig = model.phobert.forward
+    model.phobert.forward = lambda *a, **kw: (captured.append(orig(*a, **kw)), captured[-1])[1]
+    g = torch.Generator().manual_seed(11)
+    cases = [lines[40:52] + ["x", "y z w"], lines[60:63], ["p q"]]
+    for c, text in enumerate(cases):
+        sents = [ln.split(" ") for ln in text]
+        data_p = amodel.chunk_batches(amodel.process_data_parser(batch_text=sents), len(sents))
+        tok, fsw, wmask, _, _, lens = amodel.get_batch(0, data_p)
+        B, L = len(lens), max(lens)
+        head = torch.zeros(B, L - 1, dtype=torch.long)
+        rel = torch.zeros(B, L - 1, dtype=torch.long)
+        for b, ln in enumerate(lens):
+            for i in range(1, ln):  # any head but the word itself, as in a treebank (zeros stay on padding)
+                h = int(torch.randint(0, ln - 1, (1,), generator=g))
+                head[b, i - 1] = h if h < i else h + 1
+                rel[b, i - 1] = int(torch.randint(4, len(amodel.vocab["deprel"]), (1,), generator=g))
+        nwords = int(sum(lens))
+        del recorded[:]
+        with torch.no_grad():
+            loss, _ = model.dep_forward(tok, fsw, wmask, nwords, lens, head, rel, eval=False)
+        enc = captured[-1][2][-1].detach()
+        arrs[f"c{c}_enc"] = torch.stack([enc[i].index_select(0, fsw[i]) for i in range(B)]).numpy()
+        arrs[f"c{c}_lens"] = np.asarray(lens, dtype=np.int64)
+        arrs[f"c{c}_head"], arrs[f"c{c}_rel"] = head.numpy(), rel.numpy()
+        arrs[f"c{c}_nwords"] = np.int64(nwords)
+        arrs[f"c{c}_loss"] = np.float32(loss.item())
+        arrs[f"c{c}_ce"] = np.asarray(recorded, dtype=np.float32)  # arc, label, linearization
+        print(f"dep loss case {c}: B={B} L={L} loss={loss.item():.6f} ce={[round(r, 4) for r in recorded]}")
+    arrs["n_cases"] = np.int64(len(cases))
+    save("dep_loss_small.npz", **arrs)
+
+
 # ---------------------------------------------------------------------------- F7 NER entity scoring
 def gen_ner_entities():
     """Runs the reference's own score_by_entity / decode_from_bioes (models/ner/scorer.py, ner/utils.py) on random
@@ -470,6 +531,9 @@ if __name__ == "__main__":
     if "--only-trainer" in sys.argv:
         gen_trainer()
         sys.exit(0)
+    if "--only-dep-loss" in sys.argv:
+        gen_dep_loss()
+        sys.exit(0)
     torch.set_num_threads(4)
     gen_biaffine()
     gen_viterbi()
@@ -479,3 +543,4 @@ if __name__ == "__main__":
     gen_joint("joint_zero_init.npz", zero_init=True)
     gen_ner_entities()
     gen_trainer()
+    gen_dep_loss()

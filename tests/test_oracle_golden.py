@@ -115,3 +115,16 @@ def test_ner_entity_scoring(golden):
         types_ = [str(t) for t in z[f"c{c}_types"]]
         ents = [[i, st, en, types_.index(ty)] for i, p in enumerate(ps) for st, en, ty in O.decode_from_bioes(p)]
         assert ents == z[f"c{c}_pred_ents"].tolist()
+
+
+def test_dep_loss(golden):
+    """Training-side parser loss (ref models/jointmodel/model.py:209-236, dropout off) against the loss the reference's
+    dep_forward(eval=False) returned and the three sums its own crit_dep produced on the way."""
+    z = golden("dep_loss_small.npz")
+    p = _params(z)
+    for c in range(int(z["n_cases"])):
+        lens = z[f"c{c}_lens"].tolist()
+        dep = O.dep_heads(torch.from_numpy(z[f"c{c}_enc"]), lens, p)
+        total, terms = O.dep_loss(dep, lens, z[f"c{c}_head"], z[f"c{c}_rel"], int(z[f"c{c}_nwords"]))
+        np.testing.assert_allclose([float(t) for t in terms[:3]], z[f"c{c}_ce"], rtol=2e-5)
+        assert abs(float(total) - float(z[f"c{c}_loss"])) <= 2e-5 * abs(float(z[f"c{c}_loss"]))
