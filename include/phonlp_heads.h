@@ -288,6 +288,25 @@ int phonlp_ner_entity_counts(const int32_t *pred, const int32_t *gold, const int
                              int64_t *counts, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Parser training loss, forward value -- models/jointmodel/model.py:209-236 (dep_forward, eval=False branch) with
+ * every dropout the identity (no autograd):
+ *   loss[0] = arc cross-entropy (:211-216: rows 1 <= i < len, soft-max over the sentence's own columns),
+ *   loss[1] = label cross-entropy at the gold heads (:218-223, same rows),
+ *   loss[2] = linearization cross-entropy (:225-230) and loss[3] = distance term (:232-234) -- both over EVERY row
+ *             i >= 1, padded rows included, as the reference sums them (it masks neither),
+ *   loss[4] = (loss[0] + loss[1] + loss[2] + loss[3]) / number_of_words (:236).
+ * Inputs are what the eval path produces: arc_logp [B,L,L] and raw [3,B,L,L] (raw_opt) of phonlp_deep_biaffine_arc /
+ * phonlp_biaffine_arc_scores, T and XF of phonlp_label_project.  gold_head / gold_rel: int32 [B,L], column 0 (ROOT)
+ * unused, i.e. the reference's B x (L-1) tensors shifted right by one; gold_rel -1 = ignored word.  raw may be NULL
+ * when use_lin = use_dist = 0.  loss: 5 floats on the device.  Workspace: phonlp_dep_loss_ws_bytes.
+ */
+size_t phonlp_dep_loss_ws_bytes(int B, int L);
+int phonlp_dep_loss(const float *arc_logp, const float *raw, const float *T, const float *XF,
+                    const int32_t *gold_head, const int32_t *gold_rel, const int32_t *sentlens, int B, int L, int H,
+                    int O, int use_lin, int use_dist, float number_of_words, float *loss, void *ws, size_t ws_bytes,
+                    void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Per-kernel timing (no counterpart in the reference, which has no profiling: SURVEY.md section 5).
  * Between _begin and _end every kernel launch of the library is bracketed by a hipEvent pair recorded
  * on its launch stream (up to max_samples launches).  _end synchronises those events and copies the

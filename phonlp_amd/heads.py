@@ -213,6 +213,29 @@ class TaskHeads:
             out["label_scores"] = label_scores  # [B, L, O, L] -- the reference's memory order (biaffine.py:35)
         return out
 
+    # ---- training model's dep_forward(eval=False) after the gather, loss value only (ref jointmodel/model.py:209-236)
+    def parser_loss(self, enc: torch.Tensor, sentlens, gold_head, gold_rel, number_of_words=None) -> torch.Tensor:
+        """-> fp32 [5] on the device: arc CE, label CE, linearization CE, distance term, total / number_of_words --
+        what the reference's training-side `dep_forward` returns as `loss` with the model in .eval() (every dropout
+        the identity); forward value only, no autograd.  gold_head / gold_rel: the reference's B x (L-1) tensors
+        (ROOT excluded, zeros on padding) or B x L with column 0 unused.  number_of_words defaults to sum(sentlens),
+        which is what the reference's loader passes (models/jointmodel/data.py:250)."""
+        w = self.w
+        dep = self.parser(enc, sentlens, want_raw=w.n_arc_scorers > 1, want_label_argmax=False)
+        lens = dep["sentlens"]
+        B, L = enc.shape[0], enc.shape[1]
+
+        def with_root(t):
+            t = torch.as_tensor(t).to(device=enc.device, dtype=torch.int32)
+            if t.shape[1] == L - 1:
+                t = torch.nn.functional.pad(t, (1, 0))
+            return t.contiguous()
+
+        XF, T = ops.label_project(dep["hidden_out"], w.lab_W12, w.lab_b12, w.lab_Wbt, w.H, w.O)
+        nw = float(lens.sum().item()) if number_of_words is None else float(number_of_words)
+        return ops.dep_loss(dep["arc_logp"], dep.get("raw"), T, XF, with_root(gold_head), with_root(gold_rel), lens,
+                            w.H, w.O, w.linearization and w.n_arc_scorers > 1, w.distance and w.n_arc_scorers > 1, nw)
+
     # ---- decoders
     def viterbi(self, ner_logits: torch.Tensor, sentlens):
         lens = as_sentlens(sentlens, ner_logits.device)

@@ -267,6 +267,43 @@ def label_at_heads(T: Tensor, XF: Tensor, heads: Tensor, sentlens: Tensor, H: in
     return rels, best
 
 
+@torch.library.custom_op("phonlp_amd::dep_loss", mutates_args=())
+def dep_loss(arc_logp: Tensor, raw: Optional[Tensor], T: Tensor, XF: Tensor, gold_head: Tensor, gold_rel: Tensor,
+             sentlens: Tensor, H: int, O: int, use_lin: bool, use_dist: bool, number_of_words: float) -> Tensor:
+    """Parser training loss, forward value (ref models/jointmodel/model.py:209-236, dropout off) -> fp32 [5] on the
+    device: arc CE, label CE, linearization CE, distance term (sums over words), total / number_of_words.
+    gold_head / gold_rel: int32 [B,L] with column 0 = ROOT unused (include/phonlp_heads.h)."""
+    _need(arc_logp, torch.float32, "arc_logp")
+    _need(T, torch.float32, "T")
+    _need(XF, torch.float32, "XF")
+    _need(gold_head, torch.int32, "gold_head")
+    _need(gold_rel, torch.int32, "gold_rel")
+    _need(sentlens, torch.int32, "sentlens")
+    if raw is not None:
+        _need(raw, torch.float32, "raw")
+    B, L = gold_head.shape
+    if tuple(arc_logp.shape) != (B, L, L) or tuple(gold_rel.shape) != (B, L) or sentlens.numel() != B:
+        raise ValueError("dep_loss: arc_logp [B,L,L], gold_head/gold_rel [B,L], sentlens [B] expected")
+    if raw is not None and tuple(raw.shape) != (3, B, L, L):
+        raise ValueError("dep_loss: raw must be [3,B,L,L]")
+    KP = kp(H)
+    if T.numel() != B * L * O * KP or XF.numel() != B * L * 2 * KP:
+        raise ValueError("dep_loss: T [B*L, O*KP] and XF [B*L, 2*KP] of label_project expected")
+    dev = arc_logp.device
+    nb = lib().phonlp_dep_loss_ws_bytes(B, L)
+    ws = torch.empty((nb,), dtype=torch.uint8, device=dev)
+    loss = torch.empty((5,), dtype=torch.float32, device=dev)
+    check(lib().phonlp_dep_loss(_p(arc_logp), _p(raw), _p(T), _p(XF), _p(gold_head), _p(gold_rel), _p(sentlens), B, L,
+                                H, O, int(use_lin), int(use_dist), float(number_of_words), _p(loss), _p(ws), nb,
+                                _stream()), "phonlp_dep_loss")
+    return loss
+
+
+@dep_loss.register_fake
+def _(arc_logp, raw, T, XF, gold_head, gold_rel, sentlens, H, O, use_lin, use_dist, number_of_words):
+    return arc_logp.new_empty((5,))
+
+
 @torch.library.custom_op("phonlp_amd::gather_labels", mutates_args=())
 def gather_labels(label_argmax: Tensor, heads: Tensor, sentlens: Tensor) -> Tensor:
     _need(label_argmax, torch.int32, "label_argmax")

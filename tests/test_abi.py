@@ -59,6 +59,13 @@ def test_argument_errors_without_gpu(heads_lib):
     assert heads_lib.phonlp_label_stage_a_split(None, None, None, None, None, 1, 1, 400, 33, None, None) == -1
     assert heads_lib.phonlp_profile_only(b"linear:label_stage_a") == 0 and heads_lib.phonlp_profile_only(None) == 0
     assert heads_lib.phonlp_mst_ws_bytes(256, 128) > 0
+    # parser loss: NULL operands, raw scorer outputs missing, number_of_words <= 0, workspace too small
+    assert heads_lib.phonlp_dep_loss(None, None, None, None, None, None, None, 1, 2, 400, 33, 1, 1, 2.0, None, None, 0, None) == -1
+    assert b"dep_loss" in heads_lib.phonlp_last_error()
+    assert heads_lib.phonlp_dep_loss(one, None, one, one, one, one, one, 1, 2, 400, 33, 1, 0, 2.0, one, one, 64, None) == -1
+    assert heads_lib.phonlp_dep_loss(one, one, one, one, one, one, one, 1, 2, 400, 33, 1, 1, 0.0, one, one, 64, None) == -1
+    assert heads_lib.phonlp_dep_loss(one, one, one, one, one, one, one, 1, 2, 400, 33, 1, 1, 2.0, one, one, 16, None) == -2
+    assert heads_lib.phonlp_dep_loss_ws_bytes(256, 128) == 4 * 256 * 128 * 4
     assert heads_lib.phonlp_biaffine_label_ws_bytes(256, 128, 400, 33) == 256 * 128 * (2 * 408 + 33 * 408) * 4
 
 

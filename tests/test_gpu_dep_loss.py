@@ -1,0 +1,113 @@
+"""GPU parity of the training-side parser loss (phonlp_dep_loss) through the C-ABI:
+against the loss the reference's own dep_forward(eval=False) returned (tests/golden/dep_loss_small.npz, made by
+tests/golden/make_golden.py) and against the CPU oracle on synthetic batches at the real head sizes.
+Tolerance: 1e-4 relative on every sum (north star: 1e-3 on scores); the terms are sums of fp32 log-probabilities."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import heads_oracle as O  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from phonlp_amd import _lib
+    _lib.lib()  # fail loudly if the HIP library is missing
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(params=[0, 1, 2], ids=["f32mfma", "bf16x6", "f16x3"])
+def engine(request, dev):
+    from phonlp_amd import ops
+    before = ops.get_gemm_engine()
+    ops.set_gemm_engine(request.param)
+    yield request.param
+    ops.set_gemm_engine(before)
+
+
+def _params(z, prefix="p_"):
+    return {k[len(prefix):]: torch.from_numpy(z[k]) for k in z.files if k.startswith(prefix)}
+
+
+def _rel(a, b):
+    return abs(float(a) - float(b)) / max(1.0, abs(float(b)))
+
+
+def test_dep_loss_reference_fixture(dev, engine, golden):
+    from phonlp_amd import HeadWeights, TaskHeads
+    z = golden("dep_loss_small.npz")
+    heads = TaskHeads(HeadWeights.from_state_dict(_params(z), dev))
+    for c in range(int(z["n_cases"])):
+        lens = z[f"c{c}_lens"].tolist()
+        loss = heads.parser_loss(torch.from_numpy(z[f"c{c}_enc"]).to(dev), lens, torch.from_numpy(z[f"c{c}_head"]),
+                                 torch.from_numpy(z[f"c{c}_rel"]), int(z[f"c{c}_nwords"])).cpu().numpy()
+        for k in range(3):  # arc, label, linearization sums as the reference's crit_dep returned them
+            assert _rel(loss[k], z[f"c{c}_ce"][k]) <= 1e-4, (c, k, loss, z[f"c{c}_ce"])
+        assert _rel(loss[4], z[f"c{c}_loss"]) <= 1e-4, (c, loss, z[f"c{c}_loss"])
+        want_dist = float(z[f"c{c}_loss"]) * int(z[f"c{c}_nwords"]) - float(z[f"c{c}_ce"].astype(np.float64).sum())
+        assert abs(loss[3] - want_dist) <= 1e-3 * max(1.0, float(z[f"c{c}_ce"].sum()))  # a difference of large sums
+
+
+def _gold_trees(lens1, L, O_, seed):
+    g = torch.Generator().manual_seed(seed)
+    B = len(lens1)
+    head = torch.zeros(B, L, dtype=torch.int64)
+    rel = torch.zeros(B, L, dtype=torch.int64)
+    for b, ln in enumerate(lens1):
+        if ln > 1:
+            h = torch.randint(0, ln - 1, (ln - 1,), generator=g)
+            i = torch.arange(1, ln)
+            head[b, 1:ln] = torch.where(h < i, h, h + 1)  # any head but the word itself
+            rel[b, 1:ln] = torch.randint(0, O_, (ln - 1,), generator=g)
+    return head, rel
+
+
+@pytest.mark.parametrize("B,L,ragged,lin,dist", [(8, 64, True, True, True), (6, 128, False, True, True),
+                                                 (5, 40, True, False, True), (5, 40, True, True, False),
+                                                 (4, 33, True, False, False), (2, 200, True, True, True)])
+def test_dep_loss_vs_oracle(dev, engine, B, L, ragged, lin, dist):
+    from phonlp_amd import HeadWeights, TaskHeads
+    from phonlp_amd import synthetic as S
+    sd = S.make_state_dict()
+    enc_dep, _ = S.make_encoder_outputs(B, L)
+    lens1 = S.make_sentlens(B, L, ragged)
+    head, rel = _gold_trees(lens1, L, sd["deprel.scorer.W_bilin.weight"].shape[2], seed=B * 1000 + L)
+    rel[0, 1] = -1  # an ignored word (ignore_index)
+    heads = TaskHeads(HeadWeights.from_state_dict(sd, dev, linearization=lin, distance=dist))
+    got = heads.parser_loss(enc_dep.to(dev), lens1, head, rel).cpu().numpy()
+    od = O.dep_heads(enc_dep, lens1, sd, linearization=lin, distance=dist)
+    total, terms = O.dep_loss(od, lens1, head[:, 1:], rel[:, 1:], sum(lens1), linearization=lin, distance=dist)
+    for k in range(4):
+        assert _rel(got[k], terms[k]) <= 1e-4, (k, got, [float(t) for t in terms])
+    assert _rel(got[4], total) <= 1e-4
+    if not lin:
+        assert got[2] == 0.0
+    if not dist:
+        assert got[3] == 0.0
+
+
+def test_dep_loss_same_value_twice_and_argument_errors(dev):
+    """The sums are formed in a fixed order: two runs give the same bits.  Bad arguments come back as error codes."""
+    from phonlp_amd import HeadWeights, TaskHeads, ops
+    from phonlp_amd import synthetic as S
+    from phonlp_amd._lib import HeadsLibraryError
+    sd = S.make_state_dict()
+    B, L = 4, 48
+    enc_dep, _ = S.make_encoder_outputs(B, L)
+    lens1 = S.make_sentlens(B, L, True)
+    head, rel = _gold_trees(lens1, L, 33, seed=5)
+    heads = TaskHeads(HeadWeights.from_state_dict(sd, dev))
+    a = heads.parser_loss(enc_dep.to(dev), lens1, head, rel).cpu()
+    b = heads.parser_loss(enc_dep.to(dev), lens1, head[:, 1:], rel[:, 1:]).cpu()  # the reference's B x (L-1) form
+    assert torch.equal(a, b) and bool(torch.isfinite(a).all())
+    w = heads.w
+    dep = heads.parser(enc_dep.to(dev), lens1, want_raw=True, want_label_argmax=False)
+    XF, T = ops.label_project(dep["hidden_out"], w.lab_W12, w.lab_b12, w.lab_Wbt, w.H, w.O)
+    h32, r32 = head.to(dev, torch.int32), rel.to(dev, torch.int32)
+    with pytest.raises(HeadsLibraryError):  # linearization asked for without the raw scorer outputs
+        ops.dep_loss(dep["arc_logp"], None, T, XF, h32, r32, dep["sentlens"], w.H, w.O, True, True, 10.0)
+    with pytest.raises(HeadsLibraryError):
+        ops.dep_loss(dep["arc_logp"], dep["raw"], T, XF, h32, r32, dep["sentlens"], w.H, w.O, True, True, 0.0)
