@@ -306,6 +306,17 @@ int phonlp_dep_loss(const float *arc_logp, const float *raw, const float *T, con
                     int O, int use_lin, int use_dist, float number_of_words, float *loss, void *ws, size_t ws_bytes,
                     void *stream);
 
+/* POS training loss, forward value -- models/jointmodel/model.py:128-135 (pos_forward with use_soft_pos=False; crit_pos
+ * :94 = CrossEntropyLoss(ignore_index=1), mean reduction), dropout the identity:
+ *   loss[0] = mean over the words i < sentlens[b] with gold_upos != ignore_index of
+ *             logsumexp(upos_logits[b,i,:]) - upos_logits[b,i,gold]  (NaN when no word counts, as torch),
+ *   loss[1] = the sum, loss[2] = the number of words counted.
+ * upos_logits [B,L,U] as phonlp_pos_head writes them, gold_upos int32 [B,L].  The reference passes ignore_index = 1.
+ */
+size_t phonlp_pos_loss_ws_bytes(int B, int L);
+int phonlp_pos_loss(const float *upos_logits, const int32_t *gold_upos, const int32_t *sentlens, int B, int L, int U,
+                    int ignore_index, float *loss, void *ws, size_t ws_bytes, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Per-kernel timing (no counterpart in the reference, which has no profiling: SURVEY.md section 5).
  * Between _begin and _end every kernel launch of the library is bracketed by a hipEvent pair recorded

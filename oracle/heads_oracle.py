@@ -160,6 +160,16 @@ def dep_heads(enc, sentlens, p, linearization=True, distance=True, keep_label_sc
     return out
 
 
+def pos_loss(upos_logits, sentlens, gold_upos, ignore_index=1):
+    """ref: models/jointmodel/model.py:128-135 (pos_forward, use_soft_pos=False), dropout off: crit_pos (:94) =
+    CrossEntropyLoss(ignore_index=1), i.e. the MEAN cross-entropy over the sentence's own words whose gold tag is not
+    id 1 (<UNK>).  upos_logits B x L x U (``pos_head``), gold_upos B x L."""
+    B, L, U = upos_logits.shape
+    live = _row_mask(sentlens, B, L)
+    t = torch.as_tensor(gold_upos, dtype=torch.long).masked_fill(~live, ignore_index)  # pack() drops padded rows
+    return F.cross_entropy(upos_logits.reshape(-1, U), t.reshape(-1), ignore_index=ignore_index)
+
+
 def dep_loss(dep, sentlens, gold_head, gold_rel, number_of_words, linearization=True, distance=True):
     """ref: models/jointmodel/model.py:209-236 (the eval=False branch of dep_forward), dropout off.
 

@@ -1,4 +1,7 @@
-// Parser training loss, forward value (SURVEY.md section 8f row 4): ref models/jointmodel/model.py:209-236, the
+// Training-side losses of the heads as forward values: the parser loss and, at the end of
+// the file, the POS loss (the NER loss is the CRF NLL of crf.hip).
+//
+// Parser training loss, forward value: ref models/jointmodel/model.py:209-236, the
 // eval=False branch of dep_forward, with every dropout the identity (model.eval(): dev-loss monitoring; no autograd).
 //
 //   loss = ( CE_arc + CE_label + CE_lin + D ) / number_of_words, each a SUM over words (crit_dep :93: reduction "sum",
@@ -52,7 +55,8 @@ __global__ __launch_bounds__(256) void dep_loss_terms_kernel(const float *arc_lo
     const bool live = i < len;
     int h = gold_head[word];
     if (h < 0 || h >= L) h = 0;  // torch.gather would raise; read column 0 instead of faulting
-    if (tid == 0) {
+    // the two unmasked terms: one lane; on live rows it is a lane of wave 2, after the row of T has been streamed
+    auto lin_dist = [&]() {
         float t_lin = 0.f, t_dist = 0.f;
         const long e = ((long)b * L + i) * L + h;
         if (use_lin) {
@@ -68,9 +72,10 @@ __global__ __launch_bounds__(256) void dep_loss_terms_kernel(const float *arc_lo
         }
         terms[2 * M + word] = t_lin;
         terms[3 * M + word] = t_dist;
-    }
+    };
     if (!live) {  // block-uniform
         if (tid < 2) terms[tid * M + word] = 0.f;
+        if (tid == 64) lin_dist();
         return;
     }
     const int n4 = KP >> 2;
@@ -121,23 +126,28 @@ __global__ __launch_bounds__(256) void dep_loss_terms_kernel(const float *arc_lo
         for (int o = lane; o < O; o += 64) s += expf(sc[o] - m);
         s = dl_wave_sum(s);
         if (lane == 0) terms[M + word] = (r >= 0 && r < O) ? m + logf(s) - sc[r] : 0.f;  // -1 = ignore_index
+    } else if (tid == 128) {
+        lin_dist();
     }
 }
 
-// loss[0..3] = the four sums, loss[4] = their total / number_of_words.  One block; double accumulators in a fixed
-// order (thread t takes entries t, t+256, ...; then a tree over the block), so the value does not depend on timing.
-__global__ __launch_bounds__(256) void dep_loss_sum_kernel(const float *terms, long M, float number_of_words,
-                                                           float *loss) {
-    __shared__ double part[4][256];
+// loss[0..3] = the four sums, loss[4] = their total / number_of_words.  One block of 1024 threads; double accumulators
+// in a fixed order (thread t takes entries t, t+1024, ..., eight loads in flight; then a tree over the block), so the
+// value does not depend on timing.
+__global__ __launch_bounds__(1024) void dep_loss_sum_kernel(const float *terms, long M, float number_of_words,
+                                                            float *loss) {
+    __shared__ double part[4][1024];
     const int tid = threadIdx.x;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         double a = 0.0;
-        for (long e = tid; e < M; e += 256) a += (double)terms[k * M + e];
+        const float *t = terms + k * M;
+#pragma unroll 8
+        for (long e = tid; e < M; e += 1024) a += (double)t[e];
         part[k][tid] = a;
     }
     __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
+    for (int w = 512; w > 0; w >>= 1) {
         if (tid < w)
 #pragma unroll
             for (int k = 0; k < 4; ++k) part[k][tid] += part[k][tid + w];
@@ -150,6 +160,58 @@ __global__ __launch_bounds__(256) void dep_loss_sum_kernel(const float *terms, l
             tot += part[k][0];
         }
         loss[4] = (float)(tot / (double)number_of_words);
+    }
+}
+
+// POS loss (ref models/jointmodel/model.py:128-135, crit_pos :94 = CrossEntropyLoss(ignore_index=1), MEAN over the
+// words that count): one thread per word writes its cross-entropy and a 0/1 flag; rows at or beyond the sentence's
+// length (pack() drops them) and words whose gold tag is ignore_index do not count.
+__global__ __launch_bounds__(256) void pos_loss_terms_kernel(const float *logits, const int32_t *gold,
+                                                              const int32_t *sentlens, int B, int L, int U,
+                                                              int ignore_index, float *terms) {
+    const long M = (long)B * L;
+    const long word = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (word >= M) return;
+    const int b = (int)(word / L), i = (int)(word - (long)b * L);
+    const int g = gold[word];
+    float ce = 0.f, flag = 0.f;
+    if (i < sentlens[b] && g != ignore_index && g >= 0 && g < U) {
+        const float *row = logits + word * U;
+        float m = -INFINITY;
+        for (int u = 0; u < U; ++u) m = fmaxf(m, row[u]);
+        float s = 0.f;
+        for (int u = 0; u < U; ++u) s += expf(row[u] - m);
+        ce = m + logf(s) - row[g];
+        flag = 1.f;
+    }
+    terms[word] = ce;
+    terms[M + word] = flag;
+}
+
+// loss[0] = sum / count (NaN when nothing counts, as torch), loss[1] = sum, loss[2] = count; fixed summation order.
+__global__ __launch_bounds__(1024) void pos_loss_sum_kernel(const float *terms, long M, float *loss) {
+    __shared__ double part[2][1024];
+    const int tid = threadIdx.x;
+    double a = 0.0, n = 0.0;
+#pragma unroll 8
+    for (long e = tid; e < M; e += 1024) {
+        a += (double)terms[e];
+        n += (double)terms[M + e];
+    }
+    part[0][tid] = a;
+    part[1][tid] = n;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if (tid < w) {
+            part[0][tid] += part[0][tid + w];
+            part[1][tid] += part[1][tid + w];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        loss[0] = (float)(part[0][0] / part[1][0]);
+        loss[1] = (float)part[0][0];
+        loss[2] = (float)part[1][0];
     }
 }
 
@@ -186,6 +248,30 @@ extern "C" int phonlp_dep_loss(const float *arc_logp, const float *raw, const fl
         if (int rc = check_launch("dep_loss_terms_kernel")) return rc;
     }
     ProfScope ps("dep_loss_sum", st);
-    hipLaunchKernelGGL(dep_loss_sum_kernel, dim3(1), dim3(256), 0, st, terms, (long)B * L, number_of_words, loss);
+    hipLaunchKernelGGL(dep_loss_sum_kernel, dim3(1), dim3(1024), 0, st, terms, (long)B * L, number_of_words, loss);
     return check_launch("dep_loss_sum_kernel");
+}
+
+extern "C" size_t phonlp_pos_loss_ws_bytes(int B, int L) {
+    if (B <= 0 || L <= 0) return 0;
+    return (size_t)2 * B * L * sizeof(float);
+}
+
+extern "C" int phonlp_pos_loss(const float *upos_logits, const int32_t *gold_upos, const int32_t *sentlens, int B, int L,
+                               int U, int ignore_index, float *loss, void *ws, size_t ws_bytes, void *stream) {
+    if (!upos_logits || !gold_upos || !sentlens || !loss || !ws || B <= 0 || L <= 0 || U <= 0)
+        return fail(PHONLP_ERR_SHAPE, "pos_loss: bad argument");
+    if (ws_bytes < phonlp_pos_loss_ws_bytes(B, L)) return fail(PHONLP_ERR_WORKSPACE, "pos_loss: workspace too small");
+    hipStream_t st = as_stream(stream);
+    float *terms = (float *)ws;
+    const long M = (long)B * L;
+    {
+        ProfScope ps("pos_loss_terms", st);
+        hipLaunchKernelGGL(pos_loss_terms_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, upos_logits,
+                           gold_upos, sentlens, B, L, U, ignore_index, terms);
+        if (int rc = check_launch("pos_loss_terms_kernel")) return rc;
+    }
+    ProfScope ps("pos_loss_sum", st);
+    hipLaunchKernelGGL(pos_loss_sum_kernel, dim3(1), dim3(1024), 0, st, terms, M, loss);
+    return check_launch("pos_loss_sum_kernel");
 }

@@ -236,6 +236,13 @@ class TaskHeads:
         return ops.dep_loss(dep["arc_logp"], dep.get("raw"), T, XF, with_root(gold_head), with_root(gold_rel), lens,
                             w.H, w.O, w.linearization and w.n_arc_scorers > 1, w.distance and w.n_arc_scorers > 1, nw)
 
+    # ---- training model's pos_forward(use_soft_pos=False) after the gather, loss value only (ref jointmodel/model.py:128-135)
+    def pos_loss(self, enc: torch.Tensor, sentlens, gold_upos, ignore_index=1) -> torch.Tensor:
+        """-> fp32 [3] on the device: mean cross-entropy (what the reference returns as `loss`), sum, words counted."""
+        tag = self.tagger(enc, sentlens)
+        gold = torch.as_tensor(gold_upos).to(device=enc.device, dtype=torch.int32).contiguous()
+        return ops.pos_loss(tag["upos_logits"].contiguous(), gold, tag["sentlens"], ignore_index)
+
     # ---- decoders
     def viterbi(self, ner_logits: torch.Tensor, sentlens):
         lens = as_sentlens(sentlens, ner_logits.device)

@@ -304,6 +304,30 @@ def _(arc_logp, raw, T, XF, gold_head, gold_rel, sentlens, H, O, use_lin, use_di
     return arc_logp.new_empty((5,))
 
 
+@torch.library.custom_op("phonlp_amd::pos_loss", mutates_args=())
+def pos_loss(upos_logits: Tensor, gold_upos: Tensor, sentlens: Tensor, ignore_index: int) -> Tensor:
+    """POS training loss, forward value (ref models/jointmodel/model.py:128-135) -> fp32 [3] on the device: mean
+    cross-entropy over the counted words, their sum, their number."""
+    _need(upos_logits, torch.float32, "upos_logits")
+    _need(gold_upos, torch.int32, "gold_upos")
+    _need(sentlens, torch.int32, "sentlens")
+    B, L, U = upos_logits.shape
+    if tuple(gold_upos.shape) != (B, L) or sentlens.numel() != B:
+        raise ValueError("pos_loss: gold_upos [B,L] and sentlens [B] expected")
+    dev = upos_logits.device
+    nb = lib().phonlp_pos_loss_ws_bytes(B, L)
+    ws = torch.empty((nb,), dtype=torch.uint8, device=dev)
+    loss = torch.empty((3,), dtype=torch.float32, device=dev)
+    check(lib().phonlp_pos_loss(_p(upos_logits), _p(gold_upos), _p(sentlens), B, L, U, int(ignore_index), _p(loss),
+                                _p(ws), nb, _stream()), "phonlp_pos_loss")
+    return loss
+
+
+@pos_loss.register_fake
+def _(upos_logits, gold_upos, sentlens, ignore_index):
+    return upos_logits.new_empty((3,))
+
+
 @torch.library.custom_op("phonlp_amd::gather_labels", mutates_args=())
 def gather_labels(label_argmax: Tensor, heads: Tensor, sentlens: Tensor) -> Tensor:
     _need(label_argmax, torch.int32, "label_argmax")

@@ -480,6 +480,18 @@ def gen_dep_loss():
         arrs[f"c{c}_loss"] = np.float32(loss.item())
         arrs[f"c{c}_ce"] = np.asarray(recorded, dtype=np.float32)  # arc, label, linearization
         print(f"dep loss case {c}: B={B} L={L} loss={loss.item():.6f} ce={[round(r, 4) for r in recorded]}")
+        # POS loss of the same sentences (jointmodel/model.py:107-135: crit_pos, ignore_index 1, mean over the rest)
+        data_t = amodel.chunk_batches(amodel.process_data_tagger(batch_text=sents), len(sents))
+        tok_t, fsw_t, _, _, _, lens_t = amodel.get_batch(0, data_t)
+        upos = torch.randint(0, len(amodel.vocab["upos"]), (len(lens_t), max(lens_t)), generator=g)
+        with torch.no_grad():
+            ploss, ppred = model.pos_forward(tok_t, fsw_t, lens_t, use_soft_pos=False, upos=upos)
+        enc_t = captured[-1][2][-1].detach()
+        arrs[f"c{c}_tag_enc"] = torch.stack([enc_t[i].index_select(0, fsw_t[i]) for i in range(len(lens_t))]).numpy()
+        arrs[f"c{c}_tag_lens"] = np.asarray(lens_t, dtype=np.int64)
+        arrs[f"c{c}_upos"] = upos.numpy()
+        arrs[f"c{c}_pos_loss"] = np.float32(ploss.item())
+        print(f"pos loss case {c}: {ploss.item():.6f}")
     arrs["n_cases"] = np.int64(len(cases))
     save("dep_loss_small.npz", **arrs)
 

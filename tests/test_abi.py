@@ -66,6 +66,8 @@ def test_argument_errors_without_gpu(heads_lib):
     assert heads_lib.phonlp_dep_loss(one, one, one, one, one, one, one, 1, 2, 400, 33, 1, 1, 0.0, one, one, 64, None) == -1
     assert heads_lib.phonlp_dep_loss(one, one, one, one, one, one, one, 1, 2, 400, 33, 1, 1, 2.0, one, one, 16, None) == -2
     assert heads_lib.phonlp_dep_loss_ws_bytes(256, 128) == 4 * 256 * 128 * 4
+    assert heads_lib.phonlp_pos_loss(None, None, None, 1, 2, 24, 1, None, None, 0, None) == -1
+    assert heads_lib.phonlp_pos_loss(one, one, one, 1, 2, 24, 1, one, one, 8, None) == -2
     assert heads_lib.phonlp_biaffine_label_ws_bytes(256, 128, 400, 33) == 256 * 128 * (2 * 408 + 33 * 408) * 4
 
 

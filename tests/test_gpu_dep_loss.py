@@ -111,3 +111,36 @@ def test_dep_loss_same_value_twice_and_argument_errors(dev):
         ops.dep_loss(dep["arc_logp"], None, T, XF, h32, r32, dep["sentlens"], w.H, w.O, True, True, 10.0)
     with pytest.raises(HeadsLibraryError):
         ops.dep_loss(dep["arc_logp"], dep["raw"], T, XF, h32, r32, dep["sentlens"], w.H, w.O, True, True, 0.0)
+
+
+def test_pos_loss_reference_fixture(dev, engine, golden):
+    """POS loss against the value the reference's pos_forward(use_soft_pos=False) returned (crit_pos: mean,
+    ignore_index 1)."""
+    from phonlp_amd import HeadWeights, TaskHeads
+    z = golden("dep_loss_small.npz")
+    heads = TaskHeads(HeadWeights.from_state_dict(_params(z), dev))
+    for c in range(int(z["n_cases"])):
+        lens = z[f"c{c}_tag_lens"].tolist()
+        upos = z[f"c{c}_upos"]
+        got = heads.pos_loss(torch.from_numpy(z[f"c{c}_tag_enc"]).to(dev), lens, torch.from_numpy(upos)).cpu().numpy()
+        assert _rel(got[0], z[f"c{c}_pos_loss"]) <= 1e-4, (c, got, z[f"c{c}_pos_loss"])
+        counted = sum(int((upos[b, :l] != 1).sum()) for b, l in enumerate(lens))
+        assert got[2] == counted and _rel(got[1], got[0] * counted) <= 1e-5
+
+
+@pytest.mark.parametrize("B,L,ragged", [(16, 64, True), (256, 127, False), (3, 300, True)])
+def test_pos_loss_vs_oracle(dev, engine, B, L, ragged):
+    from phonlp_amd import HeadWeights, TaskHeads
+    from phonlp_amd import synthetic as S
+    sd = S.make_state_dict()
+    _, enc_tag = S.make_encoder_outputs(B, L + 1)
+    lens = [l - 1 for l in S.make_sentlens(B, L + 1, ragged)]
+    U = sd["upos_clf.weight"].shape[0]
+    gold = torch.randint(0, U, (B, L), generator=torch.Generator().manual_seed(B + L))
+    heads = TaskHeads(HeadWeights.from_state_dict(sd, dev))
+    got = heads.pos_loss(enc_tag.to(dev), lens, gold).cpu().numpy()
+    logits, _ = O.pos_head(enc_tag, lens, sd, "upos_emb_matrix_ner")
+    assert _rel(got[0], O.pos_loss(logits, lens, gold)) <= 1e-4
+    # nothing counted -> NaN, like torch's mean over an empty selection
+    none = heads.pos_loss(enc_tag.to(dev), lens, torch.ones(B, L, dtype=torch.int64)).cpu().numpy()
+    assert np.isnan(none[0]) and none[2] == 0

@@ -128,3 +128,7 @@ def test_dep_loss(golden):
         total, terms = O.dep_loss(dep, lens, z[f"c{c}_head"], z[f"c{c}_rel"], int(z[f"c{c}_nwords"]))
         np.testing.assert_allclose([float(t) for t in terms[:3]], z[f"c{c}_ce"], rtol=2e-5)
         assert abs(float(total) - float(z[f"c{c}_loss"])) <= 2e-5 * abs(float(z[f"c{c}_loss"]))
+        tl = z[f"c{c}_tag_lens"].tolist()
+        logits, _ = O.pos_head(torch.from_numpy(z[f"c{c}_tag_enc"]), tl, p, "upos_emb_matrix_ner")
+        got = float(O.pos_loss(logits, tl, z[f"c{c}_upos"]))
+        assert abs(got - float(z[f"c{c}_pos_loss"])) <= 2e-5 * abs(float(z[f"c{c}_pos_loss"]))
