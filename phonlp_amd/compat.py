@@ -212,10 +212,28 @@ def _predict_ner(self, batch, unsort=True):
     return _unsort(pred, orig_idx) if unsort else pred
 
 
+def _dev_loss(self, batch_dep=None, batch_pos=None, batch_ner=None, lambda_pos=1.0, lambda_ner=1.0, lambda_dep=1.0):
+    """The forward half of ref trainer.py:62-99 (`update`, over jointmodel/model.py:243-281) with every dropout off
+    and no backward: same batches and lambdas, same return order -- (loss, loss_pos, loss_ner, loss_dep) as floats.
+    For dev-loss monitoring; the kernels carry no autograd."""
+    h = self.model._amd_heads
+    with torch.no_grad():
+        tok, fsw, _, head, rel, nwords, _, lens = batch_dep[:8]
+        l_dep = h.parser_loss(_encode(self.model, tok, fsw), lens, head, rel, nwords)[4]
+        tok, fsw, upos, _, lens = batch_pos[:5]
+        l_pos = h.pos_loss(_encode(self.model, tok, fsw), lens, upos)[0]
+        tok, fsw, mask, tags, _, lens = batch_ner[:6]
+        tag = h.tagger(_encode(self.model, tok, fsw), lens)
+        ln, un, bi = h.crf_log_partition(tag["ner_logits"], pad_mask=mask, gold=tags)
+        l_ner = (-(un + bi - ln)).sum() / len(lens)  # CRFLoss, batch_average (crf.py:39-42)
+        loss = lambda_pos * l_pos + lambda_ner * l_ner + lambda_dep * l_dep
+    return loss.item(), l_pos.item(), l_ner.item(), l_dep.item()
+
+
 def patch_trainer(trainer, device=None, move_encoder=True):
     """The evaluation-loop twin of patch(): rebinds `predict_dep`, `predict_pos` and `predict_ner` of a reference
     `JointTrainer` (models/jointmodel/trainer.py) so that the dev/test scoring loops of the training script run the
-    heads and decoders on the MI355X.  `trainer.model` (jointmodel/model.py JointModel) keeps its encoder and its
+    heads and decoders on the MI355X, and adds `dev_loss` (the loss values of `update` on held-out batches).  `trainer.model` (jointmodel/model.py JointModel) keeps its encoder and its
     training-mode forward; only the eval-mode seams change."""
     dev = device or _dev()
     model = trainer.model
@@ -228,6 +246,7 @@ def patch_trainer(trainer, device=None, move_encoder=True):
     trainer.predict_dep = types.MethodType(_predict_dep, trainer)
     trainer.predict_pos = types.MethodType(_predict_pos, trainer)
     trainer.predict_ner = types.MethodType(_predict_ner, trainer)
+    trainer.dev_loss = types.MethodType(_dev_loss, trainer)  # no counterpart by name: `update` minus dropout and backward
     return trainer
 
 

@@ -414,6 +414,19 @@ def gen_trainer():
             arrs[f"dep_{tag}"] = np.asarray(["|".join(h + ":" + r for h, r in sent) for sent in dep])
             arrs[f"pos_{tag}"] = np.asarray(["|".join(w[0] for w in sent) for sent in pos])
             arrs[f"ner_{tag}"] = np.asarray(["|".join(sent) for sent in ner])
+    # the joint loss as JointTrainer.update forms it before backward (trainer.py:62-99 over jointmodel/model.py:243-281),
+    # with the model in .eval(): every dropout the identity.  Gold trees here never point a word at itself.
+    loss_head = torch.zeros_like(gold_head)
+    for b, ln in enumerate(lens1):
+        for i in range(1, ln):
+            h = int(torch.randint(0, ln - 1, (1,), generator=g))
+            loss_head[b, i - 1] = h if h < i else h + 1
+    with torch.no_grad():
+        lp, ln_, ld, lt, _ = trainer.model.forward(tok1, fsw1, wmask1, nw1, loss_head, gold_rel, lens1, tok, fsw, gold_upos,
+                                                  lens, tok, fsw, wmask, lens, gold_ner, 0.4, 0.2, 0.4)
+    arrs["loss_gold_head"] = loss_head.numpy()
+    arrs["joint_losses"] = np.asarray([lt.item(), lp.item(), ln_.item(), ld.item()], dtype=np.float32)  # update()'s order
+    print("joint losses (total, pos, ner, dep):", arrs["joint_losses"])
     for name, t in (("dep_tokens", tok1), ("dep_first", fsw1), ("dep_mask", wmask1), ("dep_gold_head", gold_head),
                     ("dep_gold_rel", gold_rel), ("tag_tokens", tok), ("tag_first", fsw), ("tag_mask", wmask),
                     ("gold_upos", gold_upos), ("gold_ner", gold_ner)):

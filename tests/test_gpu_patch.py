@@ -173,3 +173,21 @@ def test_patch_trainer_predict_matches_reference(golden):
                     b = rows[k]
                     assert abs(path_score(b, g_) - path_score(b, w_)) <= 1e-4 * max(1.0, abs(path_score(b, w_))), (k, g_, w_)
             assert n_diff <= 2
+
+
+def test_patch_trainer_dev_loss_matches_reference(golden):
+    """trainer.dev_loss against the four values the reference's JointModel.forward (jointmodel/model.py:243-281, the
+    forward half of JointTrainer.update) returned in .eval() mode on the same three batches, lambdas 0.4 / 0.2 / 0.4.
+    The encoder runs on the CPU (move_encoder=False) so the heads see the reference's encoder rows bit for bit."""
+    from phonlp_amd.compat import patch_trainer
+    from tests.stub_model import StubJointModel
+    z = golden("trainer_small.npz")
+    trainer = patch_trainer(_StubTrainer(StubJointModel(z)), move_encoder=False)
+    T = lambda k: torch.from_numpy(z[k])
+    dep_batch = (T("dep_tokens"), T("dep_first"), T("dep_mask"), T("loss_gold_head"), T("dep_gold_rel"),
+                 int(z["dep_nwords"]), z["dep_oidx"].tolist(), z["dep_lens"].tolist())
+    pos_batch = (T("tag_tokens"), T("tag_first"), T("gold_upos"), z["tag_oidx"].tolist(), z["tag_lens"].tolist())
+    ner_batch = (T("tag_tokens"), T("tag_first"), T("tag_mask"), T("gold_ner"), z["tag_oidx"].tolist(),
+                 z["tag_lens"].tolist())
+    got = trainer.dev_loss(dep_batch, pos_batch, ner_batch, 0.4, 0.2, 0.4)
+    np.testing.assert_allclose(got, z["joint_losses"], rtol=1e-4)
