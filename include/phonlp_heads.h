@@ -242,6 +242,18 @@ int phonlp_crf_log_partition(const float *logits, const float *trans, const uint
                              const int32_t *sentlens, const int32_t *gold_tags, int B, int L, int T,
                              float *log_norm, float *unary, float *binary, void *stream);
 
+/* Gradient of the CRF negative log-likelihood -- what autograd derives from crf.py:24-100 (CRFLoss.forward) for the
+ * emissions and the transition matrix, by forward-backward:
+ *   d_logits[b,t,c] = scale * (P(tag_t = c) - [c == gold_t]), 0 on padded steps;
+ *   d_trans[p,c]    = scale * sum_b sum_t (P(tag_{t-1} = p, tag_t = c) - [p == gold_{t-1}, c == gold_t]).
+ * scale = 1/B for the reference's batch_average (crf.py:39-40), times the incoming gradient.  pad_mask / sentlens as
+ * for phonlp_crf_log_partition.  d_logits [B,L,T], d_trans [T,T]; workspace phonlp_crf_nll_grad_ws_bytes.  T <= 64.
+ */
+size_t phonlp_crf_nll_grad_ws_bytes(int B, int T);
+int phonlp_crf_nll_grad(const float *logits, const float *trans, const uint8_t *pad_mask, const int32_t *sentlens,
+                        const int32_t *gold_tags, int B, int L, int T, float scale, float *d_logits, float *d_trans,
+                        void *ws, size_t ws_bytes, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Chu-Liu-Edmonds single-root MST -- models/common/chuliu_edmonds.py:133-169, applied to
  * arc[b, :len, :len] (rows = dependents, cols = heads, node 0 = ROOT), float64 arithmetic,

@@ -45,9 +45,28 @@ def chuliu_edmonds_one_root(scores):
     return heads[0].cpu().numpy().astype(np.int64)
 
 
+class _CRFNLL(torch.autograd.Function):
+    """Batch-averaged CRF NLL with its gradient by forward-backward on the GPU (phonlp_crf_log_partition /
+    phonlp_crf_nll_grad)."""
+
+    @staticmethod
+    def forward(ctx, x, tr, masks, tags, denom):
+        ln, un, bi = ops.crf_log_partition(x, tr, masks, None, tags)
+        ctx.save_for_backward(x, tr, masks, tags)
+        ctx.denom = denom
+        return (-(un + bi - ln)).sum() / denom
+
+    @staticmethod
+    def backward(ctx, grad):
+        x, tr, masks, tags = ctx.saved_tensors
+        dx, dtr = ops.crf_nll_grad(x, tr, masks, None, tags, 1.0 / ctx.denom)
+        return dx * grad, dtr * grad, None, None, None
+
+
 class CRFLoss(nn.Module):
     """ref models/common/crf.py:13-100.  forward(inputs, masks, tag_indices) -> (loss, transitions); masks is
-    True on padding.  Inference-side only: no autograd through the kernels."""
+    True on padding.  Differentiable: the loss carries autograd edges to `inputs` and `_transitions` whose backward is
+    the forward-backward kernel (the result lives on the GPU; gradients flow back to wherever the inputs are)."""
 
     def __init__(self, num_tag, batch_average=True):
         super().__init__()
@@ -56,15 +75,11 @@ class CRFLoss(nn.Module):
 
     def forward(self, inputs, masks, tag_indices):
         dev = _dev()
-        x = inputs.detach().to(dev, torch.float32).contiguous()
-        tr = self._transitions.detach().to(dev, torch.float32).contiguous()
-        ln, un, bi = ops.crf_log_partition(x, tr, masks.to(dev, torch.uint8).contiguous(), None,
-                                           tag_indices.to(dev, torch.int32).contiguous())
-        loss = (-(un + bi - ln)).sum()
-        if self._batch_average:
-            loss = loss / x.shape[0]
-        else:
-            loss = loss / (masks.eq(0).sum().to(dev) + 1e-8)
+        x = inputs.to(dev, torch.float32).contiguous()
+        tr = self._transitions.to(dev, torch.float32).contiguous()
+        denom = float(x.shape[0]) if self._batch_average else float(masks.eq(0).sum().item()) + 1e-8
+        loss = _CRFNLL.apply(x, tr, masks.to(dev, torch.uint8).contiguous(),
+                             tag_indices.to(dev, torch.int32).contiguous(), denom)
         return loss, self._transitions
 
 

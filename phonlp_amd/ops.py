@@ -328,6 +328,36 @@ def _(upos_logits, gold_upos, sentlens, ignore_index):
     return upos_logits.new_empty((3,))
 
 
+@torch.library.custom_op("phonlp_amd::crf_nll_grad", mutates_args=())
+def crf_nll_grad(logits: Tensor, trans: Tensor, pad_mask: Optional[Tensor], sentlens: Optional[Tensor], gold: Tensor,
+                 scale: float) -> Tuple[Tensor, Tensor]:
+    """Gradient of the CRF NLL (ref crf.py:24-100 under autograd) -> (d_logits [B,L,T], d_trans [T,T]); scale = 1/B
+    for the reference's batch average."""
+    _need(logits, torch.float32, "logits")
+    _need(trans, torch.float32, "trans")
+    _need(gold, torch.int32, "gold")
+    if pad_mask is not None:
+        _need(pad_mask, torch.uint8, "pad_mask")
+    if sentlens is not None:
+        _need(sentlens, torch.int32, "sentlens")
+    B, L, T = logits.shape
+    if tuple(trans.shape) != (T, T) or tuple(gold.shape) != (B, L):
+        raise ValueError("crf_nll_grad: trans [T,T] and gold [B,L] expected")
+    dev = logits.device
+    nb = lib().phonlp_crf_nll_grad_ws_bytes(B, T)
+    ws = torch.empty((nb,), dtype=torch.uint8, device=dev)
+    d_logits = torch.empty_like(logits)
+    d_trans = torch.empty_like(trans)
+    check(lib().phonlp_crf_nll_grad(_p(logits), _p(trans), _p(pad_mask), _p(sentlens), _p(gold), B, L, T, float(scale),
+                                    _p(d_logits), _p(d_trans), _p(ws), nb, _stream()), "phonlp_crf_nll_grad")
+    return d_logits, d_trans
+
+
+@crf_nll_grad.register_fake
+def _(logits, trans, pad_mask, sentlens, gold, scale):
+    return torch.empty_like(logits), torch.empty_like(trans)
+
+
 @torch.library.custom_op("phonlp_amd::gather_labels", mutates_args=())
 def gather_labels(label_argmax: Tensor, heads: Tensor, sentlens: Tensor) -> Tensor:
     _need(label_argmax, torch.int32, "label_argmax")

@@ -143,6 +143,13 @@ def gen_crf():
         arrs[f"c{n}_trans"] = m._transitions.detach().numpy()
         arrs[f"c{n}_log_norm"] = log_norm.numpy()
         arrs[f"c{n}_loss"] = np.float32(loss.item())
+        # the gradients the reference's own autograd derives for the emissions and the transitions
+        xg = x.clone().requires_grad_(True)
+        m._transitions.grad = None
+        lg, _ = m(xg, masks, tags)
+        lg.backward()
+        arrs[f"c{n}_d_inputs"] = xg.grad.numpy()
+        arrs[f"c{n}_d_trans"] = m._transitions.grad.numpy().copy()
         n += 1
     arrs["n"] = np.int64(n)
     save("crf.npz", **arrs)
@@ -555,6 +562,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if "--only-trainer" in sys.argv:
         gen_trainer()
+        sys.exit(0)
+    if "--only-crf" in sys.argv:
+        gen_crf()
         sys.exit(0)
     if "--only-dep-loss" in sys.argv:
         gen_dep_loss()

@@ -132,3 +132,14 @@ def test_dep_loss(golden):
         logits, _ = O.pos_head(torch.from_numpy(z[f"c{c}_tag_enc"]), tl, p, "upos_emb_matrix_ner")
         got = float(O.pos_loss(logits, tl, z[f"c{c}_upos"]))
         assert abs(got - float(z[f"c{c}_pos_loss"])) <= 2e-5 * abs(float(z[f"c{c}_pos_loss"]))
+
+
+def test_crf_nll_gradients(golden):
+    """Autograd through the oracle's crf_nll against the gradients the reference's own CRFLoss produced."""
+    z = golden("crf.npz")
+    for c in range(int(z["n"])):
+        x, m, t, tr = (torch.from_numpy(z[f"c{c}_{k}"]) for k in ("inputs", "masks", "tags", "trans"))
+        x, tr = x.clone().requires_grad_(True), tr.clone().requires_grad_(True)
+        O.crf_nll(x, m, t, tr).backward()
+        torch.testing.assert_close(x.grad, torch.from_numpy(z[f"c{c}_d_inputs"]), rtol=1e-4, atol=1e-6)
+        torch.testing.assert_close(tr.grad, torch.from_numpy(z[f"c{c}_d_trans"]), rtol=1e-4, atol=1e-6)
