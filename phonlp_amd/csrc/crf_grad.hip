@@ -94,14 +94,17 @@ __global__ __launch_bounds__(64) void crf_nll_grad_kernel(const float *logits, c
     for (int idx = lane; idx < T * T; idx += 64) dtr_part[(long)b * T * T + idx] = dtr[idx];
 }
 
-// d_trans[e] = scale * sum_b part[b][e], b ascending, double accumulator.
+// d_trans[e] = scale * sum_b part[b][e]: one wavefront per entry, lane l adds sentences l, l+64, ... in double, then a
+// fixed butterfly over the lanes -- the order of the additions never depends on timing.
 __global__ __launch_bounds__(256) void crf_dtrans_sum_kernel(const float *part, int B, int TT, float scale,
                                                              float *d_trans) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (e >= TT) return;
     double a = 0.0;
-    for (int b = 0; b < B; ++b) a += (double)part[(long)b * TT + e];
-    d_trans[e] = (float)((double)scale * a);
+    for (int b = lane; b < B; b += 64) a += (double)part[(long)b * TT + e];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+    if (lane == 0) d_trans[e] = (float)((double)scale * a);
 }
 
 }  // namespace phonlp
@@ -137,7 +140,7 @@ extern "C" int phonlp_crf_nll_grad(const float *logits, const float *trans, cons
         if (int rc = check_launch("crf_nll_grad_kernel")) return rc;
     }
     ProfScope ps("crf_dtrans_sum", st);
-    hipLaunchKernelGGL(crf_dtrans_sum_kernel, dim3(ceil_div(T * T, 256)), dim3(256), 0, st, (const float *)ws, B, T * T,
+    hipLaunchKernelGGL(crf_dtrans_sum_kernel, dim3(ceil_div(T * T, 4)), dim3(256), 0, st, (const float *)ws, B, T * T,
                        scale, d_trans);
     return check_launch("crf_dtrans_sum_kernel");
 }

@@ -41,10 +41,13 @@ t_pos = timed(lambda: ops.pos_loss(tag["upos_logits"], gold, tag["sentlens"], 1)
 nbytes = T.numel() * 4 + dep["arc_logp"].numel() * 4
 print(f"dep_loss {t_dep:.3f} ms ({nbytes / t_dep / 1e6:.0f} GB/s over T + arc_logp = {nbytes / 1e9:.2f} GB), pos_loss {t_pos:.3f} ms")
 from phonlp_amd.profile import KernelTimer
+ner_gold = torch.randint(0, w.trans.shape[0], (B, L - 1), generator=g).to(dev, torch.int32)
 with KernelTimer() as kt:
     for _ in range(10):
         ops.dep_loss(dep["arc_logp"], dep["raw"], T, XF, head, rel, dep["sentlens"], w.H, w.O, True, True, float(B * L))
         ops.pos_loss(tag["upos_logits"], gold, tag["sentlens"], 1)
+        ops.crf_log_partition(tag["ner_logits"], w.trans, None, tag["sentlens"], ner_gold)
+        ops.crf_nll_grad(tag["ner_logits"], w.trans, None, tag["sentlens"], ner_gold, 1.0 / B)
     torch.cuda.synchronize()
 for k, (n, mean, mn) in sorted(kt.stats.items()):
     print(f"  {k}: {n} launches, mean {mean * 1e3:.1f} us, min {mn * 1e3:.1f} us")
