@@ -17,10 +17,15 @@ __device__ __forceinline__ float cg_bcast(float v, int src) {
 }
 
 // Dynamic LDS: trans[TT] | dtr[TT] | emissions[L*T] | alphas[L*T]   (TT = T*T rounded up to 4 floats)
+// REG (T <= 16, the tag sets PhoNLP trains with): lane c keeps column c and row c of the transitions and its column of
+// the gradient share in registers, and the previous step's alphas come from the owning lanes by v_readlane, so the
+// inner loops touch no LDS at all; otherwise those live in LDS (lane c still owns column c of the share).
+template <bool REG>
 __global__ __launch_bounds__(64) void crf_nll_grad_kernel(const float *logits, const float *trans,
                                                           const uint8_t *pad_mask, const int32_t *sentlens,
                                                           const int32_t *gold, int L, int T, float scale,
                                                           float *d_logits, float *dtr_part) {
+    constexpr int TR = 16;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int TT = (T * T + 3) & ~3;
     float *tr = smem, *dtr = smem + TT, *sc = smem + 2 * TT, *al = sc + (long)L * T;
@@ -40,15 +45,32 @@ __global__ __launch_bounds__(64) void crf_nll_grad_kernel(const float *logits, c
 
     const bool own = lane < T;
     const int c = own ? lane : T - 1;
+    float trc[TR], trr[TR], acc[TR];  // trans[p][c], trans[c][cc], share[p][c]
+    if constexpr (REG) {
+#pragma unroll
+        for (int p = 0; p < TR; ++p) {
+            trc[p] = p < T ? tr[p * T + c] : 0.f;
+            trr[p] = p < T ? tr[c * T + p] : 0.f;
+            acc[p] = 0.f;
+        }
+    }
     // forward: alphas of every step (ref :86-98); a padded step repeats the previous row
     float alpha = sc[c];
     if (own) al[c] = alpha;
     for (int t = 1; t < L; ++t) {
         if (!is_pad(t)) {
-            float m = -INFINITY;
-            for (int p = 0; p < T; ++p) m = fmaxf(m, cg_bcast(alpha, p) + tr[p * T + c]);
-            float s = 0.f;
-            for (int p = 0; p < T; ++p) s += expf((cg_bcast(alpha, p) + tr[p * T + c]) - m);
+            float m = -INFINITY, s = 0.f;
+            if constexpr (REG) {
+#pragma unroll
+                for (int p = 0; p < TR; ++p)
+                    if (p < T) m = fmaxf(m, cg_bcast(alpha, p) + trc[p]);
+#pragma unroll
+                for (int p = 0; p < TR; ++p)
+                    if (p < T) s += expf((cg_bcast(alpha, p) + trc[p]) - m);
+            } else {
+                for (int p = 0; p < T; ++p) m = fmaxf(m, cg_bcast(alpha, p) + tr[p * T + c]);
+                for (int p = 0; p < T; ++p) s += expf((cg_bcast(alpha, p) + tr[p * T + c]) - m);
+            }
             alpha = sc[t * T + c] + (m + logf(s));
         }
         if (own) al[t * T + c] = alpha;
@@ -73,15 +95,28 @@ __global__ __launch_bounds__(64) void crf_nll_grad_kernel(const float *logits, c
         const float v = sc[t * T + c] + beta;
         const float mu = expf(al[t * T + c] + beta - logZ);
         if (own) dx[t * T + c] = scale * (mu - (c == gt ? 1.f : 0.f));
-        for (int p = 0; p < T; ++p) {  // lane c owns column c of the sentence's share: no two lanes touch one entry
-            const float xi = expf(al[(t - 1) * T + p] + tr[p * T + c] + v - logZ);
-            if (own) dtr[p * T + c] += xi - ((p == gp && c == gt) ? 1.f : 0.f);
+        float m = -INFINITY, s = 0.f;
+        if constexpr (REG) {
+            const float aprev = al[(t - 1) * T + c];  // lane p holds alpha_{t-1}[p]
+            const float w = v - logZ;
+#pragma unroll
+            for (int p = 0; p < TR; ++p)
+                if (p < T) acc[p] += expf(cg_bcast(aprev, p) + trc[p] + w) - ((p == gp && c == gt) ? 1.f : 0.f);
+#pragma unroll
+            for (int cc = 0; cc < TR; ++cc)
+                if (cc < T) m = fmaxf(m, trr[cc] + cg_bcast(v, cc));
+#pragma unroll
+            for (int cc = 0; cc < TR; ++cc)
+                if (cc < T) s += expf((trr[cc] + cg_bcast(v, cc)) - m);
+        } else {
+            for (int p = 0; p < T; ++p) {  // lane c owns column c of the sentence's share: no two lanes touch one entry
+                const float xi = expf(al[(t - 1) * T + p] + tr[p * T + c] + v - logZ);
+                if (own) dtr[p * T + c] += xi - ((p == gp && c == gt) ? 1.f : 0.f);
+            }
+            // beta of step t-1, lane = previous tag: LSE over the current tag cc of trans[lane][cc] + v[cc]
+            for (int cc = 0; cc < T; ++cc) m = fmaxf(m, tr[c * T + cc] + cg_bcast(v, cc));
+            for (int cc = 0; cc < T; ++cc) s += expf((tr[c * T + cc] + cg_bcast(v, cc)) - m);
         }
-        // beta of step t-1, lane = previous tag: LSE over the current tag cc of trans[lane][cc] + v[cc]
-        float m = -INFINITY;
-        for (int cc = 0; cc < T; ++cc) m = fmaxf(m, tr[c * T + cc] + cg_bcast(v, cc));
-        float s = 0.f;
-        for (int cc = 0; cc < T; ++cc) s += expf((tr[c * T + cc] + cg_bcast(v, cc)) - m);
         beta = m + logf(s);
     }
     {  // step 0: always inside the partition function; its gold term is masked like every other
@@ -90,8 +125,14 @@ __global__ __launch_bounds__(64) void crf_nll_grad_kernel(const float *logits, c
         const int g0 = __builtin_amdgcn_readfirstlane(g[0]);
         if (own) dx[c] = scale * (mu - ((!pad0 && c == g0) ? 1.f : 0.f));
     }
-    __syncthreads();
-    for (int idx = lane; idx < T * T; idx += 64) dtr_part[(long)b * T * T + idx] = dtr[idx];
+    if constexpr (REG) {
+#pragma unroll
+        for (int p = 0; p < TR; ++p)
+            if (p < T && own) dtr_part[(long)b * T * T + p * T + c] = acc[p];
+    } else {
+        __syncthreads();
+        for (int idx = lane; idx < T * T; idx += 64) dtr_part[(long)b * T * T + idx] = dtr[idx];
+    }
 }
 
 // d_trans[e] = scale * sum_b part[b][e]: one wavefront per entry, lane l adds sentences l, l+64, ... in double, then a
@@ -127,7 +168,9 @@ extern "C" int phonlp_crf_nll_grad(const float *logits, const float *trans, cons
     if (lds > 150 * 1024) return fail(PHONLP_ERR_UNSUPPORTED, "crf_nll_grad: L*T too large for LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)crf_nll_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void *)crf_nll_grad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void *)crf_nll_grad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024) != hipSuccess)
             return fail(PHONLP_ERR_LAUNCH, "crf_nll_grad: cannot raise the dynamic LDS limit");
         attr_set = true;
@@ -135,8 +178,12 @@ extern "C" int phonlp_crf_nll_grad(const float *logits, const float *trans, cons
     hipStream_t st = as_stream(stream);
     {
         ProfScope ps("crf_nll_grad", st);
-        hipLaunchKernelGGL(crf_nll_grad_kernel, dim3(B), dim3(64), lds, st, logits, trans, pad_mask, sentlens, gold_tags,
-                           L, T, scale, d_logits, (float *)ws);
+        if (T <= 16)
+            hipLaunchKernelGGL(crf_nll_grad_kernel<true>, dim3(B), dim3(64), lds, st, logits, trans, pad_mask, sentlens,
+                               gold_tags, L, T, scale, d_logits, (float *)ws);
+        else
+            hipLaunchKernelGGL(crf_nll_grad_kernel<false>, dim3(B), dim3(64), lds, st, logits, trans, pad_mask, sentlens,
+                               gold_tags, L, T, scale, d_logits, (float *)ws);
         if (int rc = check_launch("crf_nll_grad_kernel")) return rc;
     }
     ProfScope ps("crf_dtrans_sum", st);
