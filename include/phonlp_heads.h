@@ -329,6 +329,12 @@ size_t phonlp_pos_loss_ws_bytes(int B, int L);
 int phonlp_pos_loss(const float *upos_logits, const int32_t *gold_upos, const int32_t *sentlens, int B, int L, int U,
                     int ignore_index, float *loss, void *ws, size_t ws_bytes, void *stream);
 
+/* Gradient of that loss w.r.t. the logits, as autograd derives it from crit_pos (jointmodel/model.py:94,134):
+ * d_logits[b,i,:] = (softmax(upos_logits[b,i,:]) - onehot(gold)) / count on the words that count, 0 elsewhere.
+ * count: DEVICE pointer to the number of counted words (loss + 2 of phonlp_pos_loss), read by the kernel. */
+int phonlp_pos_loss_grad(const float *upos_logits, const int32_t *gold_upos, const int32_t *sentlens,
+                         const float *count, int B, int L, int U, int ignore_index, float *d_logits, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Per-kernel timing (no counterpart in the reference, which has no profiling: SURVEY.md section 5).
  * Between _begin and _end every kernel launch of the library is bracketed by a hipEvent pair recorded

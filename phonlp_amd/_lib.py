@@ -56,6 +56,7 @@ SIGNATURES = {
     "phonlp_dep_loss": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, ctypes.c_float, _p, _p, _z, _p]),
     "phonlp_pos_loss_ws_bytes": (_z, [_i, _i]),
     "phonlp_pos_loss": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p, _z, _p]),
+    "phonlp_pos_loss_grad": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p]),
     "phonlp_profile_begin": (_i, [_i]),
     "phonlp_profile_end": (_i, [_p, _p, _i]),
     "phonlp_profile_only": (_i, [ctypes.c_char_p]),

@@ -83,6 +83,38 @@ class CRFLoss(nn.Module):
         return loss, self._transitions
 
 
+class _PosCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, target, lens, ignore_index):
+        loss = ops.pos_loss(x, target, lens, ignore_index)
+        ctx.save_for_backward(x, target, lens, loss)
+        ctx.ignore_index = ignore_index
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, grad):
+        x, target, lens, loss = ctx.saved_tensors
+        return ops.pos_loss_grad(x, target, lens, loss, ctx.ignore_index) * grad, None, None, None
+
+
+class PosCrossEntropy(nn.Module):
+    """Drop-in for the reference's `crit_pos = nn.CrossEntropyLoss(ignore_index=1)` (models/jointmodel/model.py:94),
+    called as at :134 with packed rows: forward(logits [N, U], target [N]) -> mean cross-entropy over the targets
+    that are not `ignore_index`.  Differentiable (phonlp_pos_loss / phonlp_pos_loss_grad): assign it to
+    `model.crit_pos` and the training step's POS loss and its gradient w.r.t. the logits come from the GPU kernels."""
+
+    def __init__(self, ignore_index=1):
+        super().__init__()
+        self.ignore_index = ignore_index
+
+    def forward(self, logits, target):
+        dev = _dev()
+        x = logits.to(dev, torch.float32).contiguous().unsqueeze(0)
+        t = target.to(dev, torch.int32).contiguous().view(1, -1)
+        lens = torch.tensor([x.shape[1]], dtype=torch.int32, device=dev)
+        return _PosCE.apply(x, t, lens, self.ignore_index)
+
+
 class DeepBiaffineScorer(nn.Module):
     """ref models/common/biaffine.py:68-85 with pairwise=True (the only form the reference instantiates).
     forward(input1, input2) -> [B, L, L, O] (a non-contiguous view of [B, L, O, L] memory, like the

@@ -215,6 +215,31 @@ __global__ __launch_bounds__(1024) void pos_loss_sum_kernel(const float *terms, 
     }
 }
 
+// Gradient of the POS loss w.r.t. the logits (what autograd derives from crit_pos): (softmax - onehot) / count on the
+// words that count, 0 elsewhere; count is read from the device (loss[2] of phonlp_pos_loss), so nothing synchronises.
+__global__ __launch_bounds__(256) void pos_loss_grad_kernel(const float *logits, const int32_t *gold,
+                                                             const int32_t *sentlens, const float *count, int B, int L,
+                                                             int U, int ignore_index, float *d_logits) {
+    const long M = (long)B * L;
+    const long word = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (word >= M) return;
+    const int b = (int)(word / L), i = (int)(word - (long)b * L);
+    const int g = gold[word];
+    const float *row = logits + word * U;
+    float *out = d_logits + word * U;
+    if (i < sentlens[b] && g != ignore_index && g >= 0 && g < U) {
+        const float inv = 1.f / count[0];
+        float m = -INFINITY;
+        for (int u = 0; u < U; ++u) m = fmaxf(m, row[u]);
+        float s = 0.f;
+        for (int u = 0; u < U; ++u) s += expf(row[u] - m);
+        const float is = 1.f / s;
+        for (int u = 0; u < U; ++u) out[u] = (expf(row[u] - m) * is - (u == g ? 1.f : 0.f)) * inv;
+    } else {
+        for (int u = 0; u < U; ++u) out[u] = 0.f;
+    }
+}
+
 }  // namespace phonlp
 
 using namespace phonlp;
@@ -274,4 +299,16 @@ extern "C" int phonlp_pos_loss(const float *upos_logits, const int32_t *gold_upo
     ProfScope ps("pos_loss_sum", st);
     hipLaunchKernelGGL(pos_loss_sum_kernel, dim3(1), dim3(1024), 0, st, terms, M, loss);
     return check_launch("pos_loss_sum_kernel");
+}
+
+extern "C" int phonlp_pos_loss_grad(const float *upos_logits, const int32_t *gold_upos, const int32_t *sentlens,
+                                    const float *count, int B, int L, int U, int ignore_index, float *d_logits,
+                                    void *stream) {
+    if (!upos_logits || !gold_upos || !sentlens || !count || !d_logits || B <= 0 || L <= 0 || U <= 0)
+        return fail(PHONLP_ERR_SHAPE, "pos_loss_grad: bad argument");
+    const long M = (long)B * L;
+    ProfScope ps("pos_loss_grad", as_stream(stream));
+    hipLaunchKernelGGL(pos_loss_grad_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, as_stream(stream),
+                       upos_logits, gold_upos, sentlens, count, B, L, U, ignore_index, d_logits);
+    return check_launch("pos_loss_grad_kernel");
 }

@@ -358,6 +358,28 @@ def _(logits, trans, pad_mask, sentlens, gold, scale):
     return torch.empty_like(logits), torch.empty_like(trans)
 
 
+@torch.library.custom_op("phonlp_amd::pos_loss_grad", mutates_args=())
+def pos_loss_grad(upos_logits: Tensor, gold_upos: Tensor, sentlens: Tensor, loss: Tensor, ignore_index: int) -> Tensor:
+    """d(mean cross-entropy)/d(logits); `loss` is the fp32 [3] result of pos_loss (its count stays on the device)."""
+    _need(upos_logits, torch.float32, "upos_logits")
+    _need(gold_upos, torch.int32, "gold_upos")
+    _need(sentlens, torch.int32, "sentlens")
+    _need(loss, torch.float32, "loss")
+    B, L, U = upos_logits.shape
+    if tuple(gold_upos.shape) != (B, L) or sentlens.numel() != B or loss.numel() != 3:
+        raise ValueError("pos_loss_grad: gold_upos [B,L], sentlens [B], loss [3] expected")
+    d = torch.empty_like(upos_logits)
+    count = ctypes.c_void_p(loss.data_ptr() + 8)
+    check(lib().phonlp_pos_loss_grad(_p(upos_logits), _p(gold_upos), _p(sentlens), count, B, L, U, int(ignore_index),
+                                     _p(d), _stream()), "phonlp_pos_loss_grad")
+    return d
+
+
+@pos_loss_grad.register_fake
+def _(upos_logits, gold_upos, sentlens, loss, ignore_index):
+    return torch.empty_like(upos_logits)
+
+
 @torch.library.custom_op("phonlp_amd::gather_labels", mutates_args=())
 def gather_labels(label_argmax: Tensor, heads: Tensor, sentlens: Tensor) -> Tensor:
     _need(label_argmax, torch.int32, "label_argmax")

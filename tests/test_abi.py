@@ -71,6 +71,7 @@ def test_argument_errors_without_gpu(heads_lib):
     assert heads_lib.phonlp_crf_nll_grad(one, one, None, None, one, 1, 4, 65, 1.0, one, one, one, 1 << 20, None) == -4
     assert heads_lib.phonlp_crf_nll_grad(one, one, None, None, one, 2, 4, 9, 1.0, one, one, one, 16, None) == -2
     assert heads_lib.phonlp_pos_loss(one, one, one, 1, 2, 24, 1, one, one, 8, None) == -2
+    assert heads_lib.phonlp_pos_loss_grad(one, one, one, None, 1, 2, 24, 1, one, None) == -1
     assert heads_lib.phonlp_biaffine_label_ws_bytes(256, 128, 400, 33) == 256 * 128 * (2 * 408 + 33 * 408) * 4
 
 

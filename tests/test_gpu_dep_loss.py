@@ -144,3 +144,21 @@ def test_pos_loss_vs_oracle(dev, engine, B, L, ragged):
     # nothing counted -> NaN, like torch's mean over an empty selection
     none = heads.pos_loss(enc_tag.to(dev), lens, torch.ones(B, L, dtype=torch.int64)).cpu().numpy()
     assert np.isnan(none[0]) and none[2] == 0
+
+
+@pytest.mark.parametrize("N,U", [(1000, 24), (37, 6), (5, 70)])
+def test_pos_cross_entropy_module_backward(dev, N, U):
+    """compat.PosCrossEntropy against the reference's criterion itself -- crit_pos IS nn.CrossEntropyLoss(ignore_index=1)
+    (jointmodel/model.py:94) -- value and gradient w.r.t. the logits, on packed rows as at :134."""
+    from phonlp_amd.compat import PosCrossEntropy
+    g = torch.Generator().manual_seed(N + U)
+    x = torch.randn(N, U, generator=g) * 2
+    t = torch.randint(0, U, (N,), generator=g)
+    xr = x.clone().requires_grad_(True)
+    want = torch.nn.CrossEntropyLoss(ignore_index=1)(xr, t)
+    (3.0 * want).backward()
+    xg = x.clone().requires_grad_(True)
+    got = PosCrossEntropy()(xg, t)
+    (3.0 * got).backward()
+    assert _rel(got.detach().cpu(), want.detach()) <= 1e-5
+    torch.testing.assert_close(xg.grad, xr.grad, rtol=1e-4, atol=1e-7)
