@@ -259,10 +259,23 @@ int phonlp_crf_nll_grad(const float *logits, const float *trans, const uint8_t *
  * arc[b, :len, :len] (rows = dependents, cols = heads, node 0 = ROOT), float64 arithmetic,
  * the reference's tie-breaking and contraction order.  heads [B,L] int32 (heads[b,0] = 0;
  * entries >= len set to 0); status [B] int32 (PHONLP_MST_*).  One workgroup per sentence.
+ *
+ * Two decoders produce these trees.  The reference-order kernel replays the reference's one-cycle-per-level
+ * recursion step by step.  The round-based kernel (L <= 128, on by default) contracts every cycle of a round together
+ * and is used per sentence only where it provably returns the reference's tree: all of the reference's float64 sums
+ * are exact for that sentence's scores and every selection has a strictly unique maximum (csrc/mst_fast.hip); any
+ * other sentence (ties, integer-valued scores, denormals, NaN) is decoded by the reference-order kernel in the same
+ * call.  phonlp_set_mst_fast_path(0) sends every sentence to the reference-order kernel (A/B and tests; process-wide,
+ * not thread-safe); phonlp_mst_fallback_counter_offset gives the byte offset inside `ws` of an int32 that holds, after
+ * the call, how many sentences were handed over (-1 if the round-based kernel does not apply to this L).
  */
 size_t phonlp_mst_ws_bytes(int B, int L);
 int phonlp_mst_one_root(const float *arc, const int32_t *sentlens, int B, int L,
                         int32_t *heads, int32_t *status, void *ws, size_t ws_bytes, void *stream);
+int phonlp_set_mst_fast_path(int on);
+int phonlp_get_mst_fast_path(void);
+long phonlp_mst_fallback_counter_offset(int B, int L);
+long phonlp_mst_fallback_list_offset(int B, int L); /* int32 [B]: sentence | reason << 24 (1 inexact, 2/3 a tie) */
 
 /* Decode glue -- annotate_model.py:263-266: rel[b,i] = label_argmax[b, i, heads[b,i]] for
  * 1 <= i < len, 0 elsewhere. */

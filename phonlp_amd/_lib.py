@@ -40,6 +40,10 @@ SIGNATURES = {
     "phonlp_crf_nll_grad": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, ctypes.c_float, _p, _p, _p, _z, _p]),
     "phonlp_mst_ws_bytes": (_z, [_i, _i]),
     "phonlp_mst_one_root": (_i, [_p, _p, _i, _i, _p, _p, _p, _z, _p]),
+    "phonlp_set_mst_fast_path": (_i, [_i]),
+    "phonlp_get_mst_fast_path": (_i, []),
+    "phonlp_mst_fallback_counter_offset": (ctypes.c_long, [_i, _i]),
+    "phonlp_mst_fallback_list_offset": (ctypes.c_long, [_i, _i]),
     "phonlp_ner_entity_counts": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p, _p]),
     "phonlp_label_project": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "phonlp_label_at_heads": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p]),

@@ -39,6 +39,16 @@ def stale():
     return any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps)
 
 
+def build_stamps(verbose=True):
+    """Diagnostic variant (tools/mst_stamps.py): the MST kernels with per-phase cycle counters (-DMST_STAMPS)."""
+    out = os.path.join(HERE, "..", "tools", "libphonlp_heads_stamps.so")
+    cmd = [HIPCC] + FLAGS + ["-DMST_STAMPS", "-shared", "-o", out] + sources()
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return out
+
+
 def build(force=False, verbose=True):
     if not force and not stale():
         return LIB
@@ -64,4 +74,7 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    if "--stamps" in sys.argv:
+        build_stamps()
+    else:
+        build(force="--force" in sys.argv)

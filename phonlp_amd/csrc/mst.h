@@ -27,7 +27,8 @@ struct MstArgs {
     int32_t *cand_root;    // [B][L] candidate roots, ascending
     double *cand_score;    // [B][L]
     uint32_t *cand_tree;   // [B][L][Lw] candidate trees, one byte per node, Lw = ceil(L/4) words
-    int max_waiters;       // workgroups allowed to wait for late candidates at one time (they hold a CU's LDS)
+    // mst_fast.hip: sentences the round-based decode could not prove itself on (ties, inexact sums); count in ctr[CT_FB]
+    int32_t *fb_list;      // [B] or NULL (mst_wave_kernel then decodes every sentence)
     // mst.hip, two-phase form for sentences too long for the wave kernel: mode 0 = everything in one workgroup per
     // sentence; mode 1 = the unconstrained decode only (a sentence with >= 2 children of ROOT is left PENDING with its
     // tree in tree0g); mode 2 = grid of B x cslots workgroups, workgroup (b, s) decodes candidates s, s + cslots, ...
@@ -39,7 +40,11 @@ struct MstArgs {
     uint16_t *cs_tree;     // [B][cslots][L] its tree
 };
 
-#define PHONLP_MST_PENDING 3  // internal: between the phases of the two-phase form
+#define PHONLP_MST_PENDING 3   // internal: between the phases of the two-phase form
+#define PHONLP_MST_FALLBACK 4  // internal: mst_fast.hip hands the sentence to the reference-order kernel
+
+// counters at the head of the shared region (zeroed per call): candidate queue tail / head, fallback count
+enum { CT_STARTED = 0, CT_FIRST_DONE = 1, CT_Q_TAIL = 2, CT_Q_HEAD = 3, CT_FB = 5, CT_COUNT = 8 };
 
 #ifdef MST_STAMPS
 #define STAMP(k)                                              \
@@ -92,6 +97,13 @@ bool mst_wave_fits(int L);
 size_t mst_share_bytes(int B, int L);
 void mst_share_carve(MstArgs &a, void *base);
 size_t mst_share_zero_bytes(int B, int L);  // leading part of the region that every launch clears
+int launch_mst_clear(const MstArgs &a, hipStream_t stream);
 int launch_mst_wave(MstArgs a, hipStream_t stream);
+
+// mst_fast.hip
+bool mst_fast_fits(int L);
+size_t mst_fast_bytes(int B, int L);
+void mst_fast_carve(MstArgs &a, void *base);
+int launch_mst_fast(MstArgs a, hipStream_t stream);
 
 }  // namespace phonlp

@@ -447,13 +447,42 @@ static size_t mst_two_phase_bytes(int B, int L) {
            align_up(q * sizeof(double), 256) + align_up(q * sizeof(int32_t), 256) + align_up(q * L * sizeof(uint16_t), 256);
 }
 
-extern "C" size_t phonlp_mst_ws_bytes(int B, int L) {
+// offset of the shared region (candidate queue, counters) of the wave / round-based kernels inside the workspace
+static size_t mst_share_offset(int B, int L) {
     const size_t regions = mst_regions(B, L);
-    size_t bytes = align_up(regions * L * mst_lvl_stride(L) * sizeof(uint16_t), 256);
-    if (!mst_fits_lds(L)) bytes += align_up(regions * L * mst_pitch(L) * sizeof(double), 256);
-    if (mst_wave_fits(L)) bytes += mst_share_bytes(B, L);
-    else if (!mst_fits_lds(L)) bytes += mst_two_phase_bytes(B, L);
+    size_t off = align_up(regions * L * mst_lvl_stride(L) * sizeof(uint16_t), 256);
+    if (!mst_fits_lds(L)) off += align_up(regions * L * mst_pitch(L) * sizeof(double), 256);
+    return off;
+}
+
+extern "C" size_t phonlp_mst_ws_bytes(int B, int L) {
+    size_t bytes = mst_share_offset(B, L);
+    if (mst_wave_fits(L)) {
+        bytes += mst_share_bytes(B, L);
+        if (mst_fast_fits(L)) bytes += mst_fast_bytes(B, L);
+    } else if (!mst_fits_lds(L)) {
+        bytes += mst_two_phase_bytes(B, L);
+    }
     return bytes;
+}
+
+static int g_mst_fast = -1;  // -1: not decided yet ($PHONLP_MST_FAST, default on)
+static bool mst_fast_enabled() {
+    if (g_mst_fast < 0) g_mst_fast = getenv("PHONLP_MST_FAST") ? (atoi(getenv("PHONLP_MST_FAST")) != 0) : 1;
+    return g_mst_fast != 0;
+}
+extern "C" int phonlp_set_mst_fast_path(int on) {
+    g_mst_fast = on ? 1 : 0;
+    return PHONLP_OK;
+}
+extern "C" int phonlp_get_mst_fast_path(void) { return mst_fast_enabled() ? 1 : 0; }
+extern "C" long phonlp_mst_fallback_counter_offset(int B, int L) {
+    if (B <= 0 || L <= 0 || !mst_wave_fits(L) || !mst_fast_fits(L)) return -1;
+    return (long)(mst_share_offset(B, L) + CT_FB * sizeof(int32_t));
+}
+extern "C" long phonlp_mst_fallback_list_offset(int B, int L) {
+    if (B <= 0 || L <= 0 || !mst_wave_fits(L) || !mst_fast_fits(L)) return -1;
+    return (long)(mst_share_offset(B, L) + mst_share_bytes(B, L));
 }
 
 extern "C" int phonlp_mst_one_root(const float *arc, const int32_t *sentlens, int B, int L, int32_t *heads,
@@ -486,10 +515,20 @@ extern "C" int phonlp_mst_one_root(const float *arc, const int32_t *sentlens, in
     ProfScope ps("mst", as_stream(stream));
     const size_t regions = mst_regions(B, L);
     const size_t stack_bytes = align_up(regions * L * a.lvl_stride * sizeof(uint16_t), 256);
-    if (mst_wave_fits(L) && !getenv("PHONLP_MST_BLOCKSYNC")) {
-        size_t off = stack_bytes;
-        if (!in_lds) off += align_up(regions * L * a.pitch * sizeof(double), 256);
+    static const bool blocksync = getenv("PHONLP_MST_BLOCKSYNC") != nullptr;  // A/B: the block-synchronous kernel for every L
+    if (mst_wave_fits(L) && !blocksync) {
+        const size_t off = mst_share_offset(B, L);
         mst_share_carve(a, (char *)ws + off);
+        int rc = launch_mst_clear(a, as_stream(stream));
+        if (rc) return rc;
+        if (mst_fast_enabled() && mst_fast_fits(L)) {
+            // round-based decode where it provably returns the reference's tree; the rest lands on the fallback list,
+            // which the reference-order kernel below then decodes (usually nothing)
+            mst_fast_carve(a, (char *)ws + off + mst_share_bytes(B, L));
+            rc = launch_mst_fast(a, as_stream(stream));
+            if (rc) return rc;
+            a.dbg = nullptr;  // diagnostic builds: the counters are the round-based kernel's
+        }
         return launch_mst_wave(a, as_stream(stream));
     }
     if (in_lds) {

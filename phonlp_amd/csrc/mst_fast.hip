@@ -1,0 +1,804 @@
+// Chu-Liu-Edmonds single-root MST, round-based decode ("every cycle of a round contracted together").
+//
+// The reference (models/common/chuliu_edmonds.py:52-129) contracts ONE cycle per recursion level; mst_wave.hip /
+// mst.hip replay that order bit for bit and need ~100 dependent levels per 128-word sentence.  This kernel finds the
+// same tree with ~40 much cheaper rounds, and is used only where it PROVABLY returns the reference's tree:
+//
+//  (G) exactness.  Every finite entry of the sentence's matrix (rows >= 1, off the diagonal) is a multiple of
+//      2^lo with |entry| < 2^hi, and hi - lo + ceil(log2 l) + 1 <= 52.  Every value the reference forms in float64 --
+//      contracted entries (s - e) + total (:84), cycle sums (:75), tree scores (:158) -- is, in exact arithmetic, a
+//      signed sum of at most 2l original entries, so under (G) none of its additions rounds: the reference runs EXACT
+//      Chu-Liu-Edmonds (with its own tie-breaking) and returns A maximum arborescence.  The same holds for the sums
+//      formed here.
+//  (U) uniqueness.  Every selection made here -- the best head of a row among the columns outside its component, the
+//      best row of a component -- has a strictly unique, finite maximum.  Then the maximum arborescence is unique:
+//      if every node of the current contracted graph has a strictly best in-edge and those edges close a cycle C,
+//      every maximum arborescence contains all of C's edges but one (re-hanging the other members of C on their cycle
+//      edge strictly improves any other tree), so maximum arborescences of the graph and of the graph with C
+//      contracted correspond one to one; contracting C leaves the strict maxima of all other rows strict (the new
+//      column is a maximum over old columns and is ordered last).  By induction over the rounds the tree is unique,
+//      and any correct variant of the algorithm -- the reference's included -- returns it.
+//
+//  A sentence that fails (G) or (U) anywhere (ties, denormals, NaN, more rounds than the history holds) gets status
+//  PHONLP_MST_FALLBACK and is decoded by the reference-order kernel afterwards (launch_mst_wave over the fallback
+//  list).  Integer-valued or zero matrices (all ties) therefore take the old path; float log-probabilities take this one.
+//
+// Formulation.  The matrix is never rewritten.  comp[i] = component (contracted node) of word i; off[i] = what the
+// reference has added to row i's entries so far (for every member m of a contracted cycle: total - e_m, :84), which is
+// the same for every column.  The contracted row of a component X -- the reference's metanode row, max over the rows i
+// of X of W[i][j] + off[i] for every column j -- is kept as ONE BYTE per column: A[X][j] = the row that attains it
+// (bit 7: attained by more than one row).  Merging a cycle is then, per column, a maximum over the members' bytes
+// (two or three gathers per member, all columns in parallel), and the new component's in-edge an arg-max over the
+// columns outside it.  A round: heads of the components -> cycles (full pointer doubling in round 0; afterwards a
+// bounded walk from the components created in the previous round, since a new cycle must pass through one of them
+// and a component whose path reaches ROOT stays that way for good) -> every cycle labelled, offsets updated -> the new
+// components' rows merged and their in-edges chosen, four components per pass on 16 lanes each.  One wavefront runs
+// the rounds without barriers (LDS operations of a wave execute in order); the whole workgroup does the two O(l^2)
+// steps (load + exactness check, first arg-max of every row).
+//
+// Expansion (:105-128 in one sweep per round, backwards): per round the component of every word and the in-edge of
+// every component BEFORE the merge are kept (3 bytes per word and round); a component keeps the real in-edge of the
+// component it was merged into if that edge enters one of its own words, and its own recorded in-edge otherwise.
+//
+// Single-root logic (:137-169) as in mst.hip's two-phase form: phase 1 decodes the unconstrained tree of every
+// sentence; phase 2 decodes the candidates of the sentences with several children of ROOT on a B x 4 grid
+// (set_root's edits :143-149 are applied while scanning, the matrix in LDS stays the original); the pick kernel takes
+// the greatest score, lowest candidate number among equals (= strict '>' in candidate order, :159).
+#include "mst.h"
+
+namespace phonlp {
+
+#define WFENCE() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
+
+constexpr int kFastSlots = 4;
+constexpr int kWalkMax = 4;
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140;
+enum { FS_LO = 0, FS_HI, FS_BAD, FS_FAIL, FS_NNEW, FS_CMD, FS_BAD2, FS_COUNT = 16 };
+enum { CMD_GO = 1, CMD_DONE = 2 };
+constexpr int HC_SETTLED = 0x8000, HC_NEW = 0x4000, HC_MASK = 0x3FFF;
+
+struct FastLayout {
+    size_t off_d, off_a, off_i, off_hist, total;
+    int pitch, hist_cap;
+};
+constexpr int kFastIntArrays = 13;
+static FastLayout fast_layout(int L) {
+    FastLayout f;
+    f.pitch = (L + 47) / 64 * 64 + 16;  // smallest p >= L with p % 64 == 16: four consecutive rows hit disjoint banks
+    f.off_d = (size_t)L * f.pitch * sizeof(float);
+    f.off_a = f.off_d + (size_t)3 * L * sizeof(double);
+    f.off_i = f.off_a + align_up((size_t)L * L, 16);
+    f.off_hist = f.off_i + ((size_t)kFastIntArrays * L + FS_COUNT) * sizeof(int);
+    const long room = 160L * 1024 - (long)f.off_hist;
+    long cap = room / (3L * L) - 1;
+    if (cap > L) cap = L;
+    f.hist_cap = cap > 0 ? (int)cap : 0;
+    f.total = f.off_hist + (size_t)(f.hist_cap + 1) * 3 * L;
+    return f;
+}
+bool mst_fast_fits(int L) { return L >= 2 && L <= 128 && fast_layout(L).hist_cap >= 16; }
+
+template <int CTRL>
+__device__ __forceinline__ int fdpp_i(int v) {
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false);
+}
+template <int CTRL>
+__device__ __forceinline__ double fdpp_d(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = fdpp_i<CTRL>((int)(b & 0xFFFFFFFFll)), hi = fdpp_i<CTRL>((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+// (value, index, duplicate) arg-max over the 16 lanes of a row: greatest value; `dup` set when the maximum is not unique
+template <int CTRL>
+__device__ __forceinline__ void fast_argmax_step(float &bv, int &bi, int &dup) {
+    const float v2 = __int_as_float(fdpp_i<CTRL>(__float_as_int(bv)));
+    const int i2 = fdpp_i<CTRL>(bi);
+    const int d2 = fdpp_i<CTRL>(dup);
+    const bool gt = v2 > bv, eq = v2 == bv;
+    dup = gt ? d2 : (eq ? 1 : dup);
+    bi = gt ? i2 : ((eq && i2 < bi) ? i2 : bi);
+    bv = gt ? v2 : bv;
+}
+// the same for the contracted rows: (value, column | row byte << 8, duplicate)
+template <int CTRL>
+__device__ __forceinline__ void fast_argmax_step_d(double &bv, int &bi, int &dup) {
+    const double v2 = fdpp_d<CTRL>(bv);
+    const int i2 = fdpp_i<CTRL>(bi);
+    const int d2 = fdpp_i<CTRL>(dup);
+    const bool gt = v2 > bv, eq = v2 == bv;
+    dup = gt ? d2 : (eq ? 1 : dup);
+    bi = gt ? i2 : bi;
+    bv = gt ? v2 : bv;
+}
+
+// best column of one row among the columns other than `row` itself (and not column 0 when `skip0`), by 16 lanes
+template <int NC>
+__device__ __forceinline__ void fast_scan_row16(const float *Wrow, int row, int n, int sub, bool skip0, float &bv,
+                                                int &bi, int &dup) {
+    float vals[NC];
+#pragma unroll
+    for (int t = 0; t < NC; ++t) vals[t] = (sub + 16 * t < n) ? Wrow[sub + 16 * t] : -__builtin_inff();
+    bv = -__builtin_inff();
+    bi = INT_MAX;
+    dup = 0;
+#pragma unroll
+    for (int t = 0; t < NC; ++t) {
+        const int j = sub + 16 * t;
+        const bool ok = j < n && j != row && !(skip0 && j == 0);
+        const float v = ok ? vals[t] : -__builtin_inff();
+        const bool gt = v > bv, eq = ok && v == bv;
+        dup = gt ? 0 : (dup | (eq ? 1 : 0));
+        bi = gt ? j : bi;
+        bv = gt ? v : bv;
+    }
+    fast_argmax_step<DPP_XOR1>(bv, bi, dup);
+    fast_argmax_step<DPP_XOR2>(bv, bi, dup);
+    fast_argmax_step<DPP_HALF_MIRROR>(bv, bi, dup);
+    fast_argmax_step<DPP_MIRROR>(bv, bi, dup);
+}
+
+#ifdef MST_STAMPS
+#define FCOUNT(k, v) do { if (tid == 0) stamp_acc[k] += (v); } while (0)
+#else
+#define FCOUNT(k, v) do {} while (0)
+#endif
+
+template <int NPL>
+__global__ __launch_bounds__(256) void mst_fast_kernel(MstArgs a, int pitch, int hist_cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sub = lane & 15;
+#ifdef MST_STAMPS
+    long long stamp_acc[16] = {0};
+    long long stamp_t = clock64();
+#endif
+    const int L = a.L, mode = a.mode, CS = a.cslots;
+    const int b = mode == 2 ? blockIdx.x / CS : blockIdx.x;
+    const int slot = mode == 2 ? blockIdx.x % CS : 0;
+    int l = a.sentlens[b];
+    if (l > L) l = L;
+    int32_t *hout = a.heads + (long)b * L;
+    int ncand = 1;
+    if (mode == 2) {
+        if (a.status[b] != PHONLP_MST_PENDING) return;
+        ncand = a.cand_n[b];
+        if (slot >= ncand) return;
+    } else {
+        for (int t = tid; t < L; t += 256) hout[t] = 0;
+        if (l <= 1) {  // l == 1: ROOT only -- the reference hits its broken assert (no candidate root)
+            if (tid == 0) a.status[b] = l == 1 ? PHONLP_MST_NO_FINITE_TREE : PHONLP_MST_OK;
+            return;
+        }
+    }
+    float *W = reinterpret_cast<float *>(smem_raw);
+    double *selV = reinterpret_cast<double *>(smem_raw + (size_t)L * pitch * sizeof(float));
+    double *dlt = selV + L, *offL = dlt + L;
+    unsigned char *A = reinterpret_cast<unsigned char *>(offL + L);
+    int *comp = reinterpret_cast<int *>(A + align_up((size_t)L * L, 16));
+    int *bjL = comp + L, *hcAw = bjL + L, *selI = hcAw + L, *selJ = selI + L, *lab = selJ + L, *cycf = lab + L;
+    int *claim = cycf + L, *pool = claim + L, *newlist = pool + L, *rI = newlist + L, *rJ = rI + L;
+    float *bvL = reinterpret_cast<float *>(rJ + L);
+    int *sc = reinterpret_cast<int *>(bvL + L);
+    unsigned char *hist = reinterpret_cast<unsigned char *>(sc + FS_COUNT);
+    const float *arc = a.arc + (long)b * L * L;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const float NEGF = -__builtin_inff();
+
+    // ---- whole workgroup: the matrix into LDS (fp32, as given) and, in phase 1, the exactness test (G)
+    if (tid == 0) { sc[FS_LO] = INT_MAX; sc[FS_HI] = INT_MIN; sc[FS_BAD] = 0; }
+    __syncthreads();
+    {
+        int lo = INT_MAX, hi = INT_MIN, bad = 0;
+        for (int i0 = wave; i0 < l; i0 += 32) {
+            float vals[8][NPL];
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) {
+                    const int i = i0 + 4 * r, j = lane + 64 * q;
+                    vals[r][q] = (i < l && j < l) ? arc[(long)i * L + j] : 0.f;
+                }
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) {
+                    const int i = i0 + 4 * r, j = lane + 64 * q;
+                    if (i < l && j < l) {
+                        W[i * pitch + j] = vals[r][q];
+                        if (i >= 1 && i != j) {
+                            const unsigned bits = __float_as_uint(vals[r][q]);
+                            const int e = (bits >> 23) & 0xFF;
+                            const unsigned man = bits & 0x7FFFFFu;
+                            if (e == 255) { if (man != 0 || !(bits >> 31)) bad = 1; }      // NaN, +inf (-inf = no edge)
+                            else if (e == 0) { if (man != 0) bad = 1; }                    // denormal (zero is on every grid)
+                            else {
+                                const int tz = __builtin_ctz(man | 0x800000u);
+                                const int elo = e - 150 + tz, ehi = e - 126;
+                                lo = elo < lo ? elo : lo;
+                                hi = ehi > hi ? ehi : hi;
+                            }
+                        }
+                    }
+                }
+        }
+        if (mode == 1) {
+            if (lo != INT_MAX) { atomicMin(&sc[FS_LO], lo); atomicMax(&sc[FS_HI], hi); }
+            if (bad) sc[FS_BAD] = 1;
+        }
+    }
+    __syncthreads();
+    if (mode == 1) {
+        int nbits = 1;
+        while ((1 << (nbits - 1)) < l) ++nbits;  // ceil(log2 l) + 1
+        const int lo = sc[FS_LO], hi = sc[FS_HI];
+        const int q = lo < 0 ? -lo : 0;
+        const bool exact = !sc[FS_BAD] && (lo == INT_MAX || hi + q + nbits <= 52);
+        STAMP(0);
+        if (!exact) {  // block-uniform
+            if (tid == 0) {
+                a.status[b] = PHONLP_MST_FALLBACK;
+                a.fb_list[atomicAdd(&a.ctr[CT_FB], 1)] = b | (1 << 24);  // bits 24+: why (diagnostics): 1 = (G)
+            }
+            return;
+        }
+    }
+
+    double best_score = NEG_INF_D;
+    int best_ci = -1, failed = 0;
+    for (int ci = slot; ci < ncand; ci += CS) {  // phase 1: one trip; phase 2: this slot's candidates
+        const int root = mode == 2 ? a.cand_root[(long)b * L + ci] : -1;
+        const bool skip0 = root >= 1;
+        // ---- whole workgroup: first arg-max of every row (ref :58), component state
+        if (tid == 0) { sc[FS_FAIL] = 0; sc[FS_CMD] = CMD_GO; sc[FS_BAD2] = 0; }
+        for (int t = tid; t < l; t += 256) { comp[t] = t; cycf[t] = 0; lab[t] = t; offL[t] = 0.0; }
+        for (int t = tid; t < l * (L / 4); t += 256) {  // A[X][j] = X: a word is its own component's only row
+            const int X = t / (L / 4);
+            reinterpret_cast<unsigned *>(A)[t] = 0x01010101u * (unsigned)X;
+        }
+        __syncthreads();
+        for (int row = 1 + (tid >> 4); row < l; row += 16) {
+            float bv; int bi, dup;
+            fast_scan_row16<4 * NPL>(W + row * pitch, row, l, sub, skip0, bv, bi, dup);
+            if (row == root) { bv = 0.f; bi = 0; dup = 0; }  // set_root: the row's only edge, weight 0 (:147-148)
+            if (sub == 0) {
+                bjL[row] = bi;
+                bvL[row] = bv;
+                selI[row] = row;
+                selJ[row] = bi;
+                selV[row] = (double)bv;
+                if (dup || !(bv > NEGF)) sc[FS_FAIL] = 1;
+            }
+        }
+        __syncthreads();
+        STAMP(1);
+        int fail_ = sc[FS_FAIL];  // block-uniform
+        // Contracted row and in-edge of the new components of a round, one component per wavefront (lane = column):
+        // per column the best member row (:84,:88,:97; A holds the row, bit 7 = more than one), then the strictly best
+        // column outside the component.  Run by all four wavefronts between two workgroup barriers.
+        auto merge_pass = [&](int nnew) {
+            int ccol[NPL];
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) ccol[q] = (lane + 64 * q < l) ? comp[lane + 64 * q] : -1;
+#pragma unroll 1
+            for (int p = 0; p + wave < nnew; p += 4) {
+                const int d = newlist[p + wave];
+                const int R = d & 0xFF, po = (d >> 8) & 0xFF, c = (d >> 16) & 0xFF;
+                double cv[NPL];
+                int ca[NPL];
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) { cv[q] = NEG_INF_D; ca[q] = 0; }
+#pragma unroll 1
+                for (int k = 0; k < c; k += 2) {  // two members per trip: their loads are in flight together
+                    const bool two = k + 1 < c;
+                    const int m0 = pool[po + k], m1 = pool[po + (two ? k + 1 : k)];
+                    int a0[NPL], a1[NPL];
+#pragma unroll
+                    for (int q = 0; q < NPL; ++q) {
+                        const int j = (lane + 64 * q < l) ? lane + 64 * q : 0;
+                        a0[q] = A[m0 * L + j];
+                        a1[q] = A[m1 * L + j];
+                    }
+                    float w0[NPL], w1[NPL];
+                    double o0[NPL], o1[NPL];
+#pragma unroll
+                    for (int q = 0; q < NPL; ++q) {
+                        const int j = (lane + 64 * q < l) ? lane + 64 * q : 0;
+                        w0[q] = W[(a0[q] & 0x7F) * pitch + j];
+                        o0[q] = offL[a0[q] & 0x7F];
+                        w1[q] = W[(a1[q] & 0x7F) * pitch + j];
+                        o1[q] = offL[a1[q] & 0x7F];
+                    }
+#pragma unroll
+                    for (int q = 0; q < NPL; ++q) {  // selects, not control flow
+                        const double v0 = (double)w0[q] + o0[q];
+                        const bool gt0 = v0 > cv[q], eq0 = v0 == cv[q];
+                        ca[q] = gt0 ? a0[q] : (ca[q] | (eq0 ? 0x80 : 0));  // bit 7: two rows attain it (checked if chosen)
+                        cv[q] = gt0 ? v0 : cv[q];
+                        const double v1 = two ? (double)w1[q] + o1[q] : NEG_INF_D;
+                        const bool gt1 = v1 > cv[q], eq1 = two && v1 == cv[q];
+                        ca[q] = gt1 ? a1[q] : (ca[q] | (eq1 ? 0x80 : 0));
+                        cv[q] = gt1 ? v1 : cv[q];
+                    }
+                }
+                double bv = NEG_INF_D;
+                int bi = 0, dup = 0;
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) {
+                    const int j = lane + 64 * q;
+                    if (j < l) A[R * L + j] = (unsigned char)ca[q];
+                    const bool ok = j < l && ccol[q] != R && !(skip0 && j == 0);
+                    const double v = ok ? cv[q] : NEG_INF_D;
+                    const bool gt = v > bv, eq = ok && v == bv;
+                    dup = gt ? 0 : (dup | (eq ? 1 : 0));
+                    bi = gt ? (j | (ca[q] << 8)) : bi;
+                    bv = gt ? v : bv;
+                }
+                fast_argmax_step_d<DPP_XOR1>(bv, bi, dup);
+                fast_argmax_step_d<DPP_XOR2>(bv, bi, dup);
+                fast_argmax_step_d<DPP_HALF_MIRROR>(bv, bi, dup);
+                fast_argmax_step_d<DPP_MIRROR>(bv, bi, dup);
+#pragma unroll
+                for (int o = 16; o <= 32; o <<= 1) {
+                    const double v2 = __shfl_xor(bv, o);
+                    const int i2 = __shfl_xor(bi, o), d2 = __shfl_xor(dup, o);
+                    const bool gt = v2 > bv, eq = v2 == bv;
+                    dup = gt ? d2 : (eq ? 1 : dup);
+                    bi = gt ? i2 : bi;
+                    bv = gt ? v2 : bv;
+                }
+                if (lane == 0) {
+                    selI[R] = (bi >> 8) & 0x7F;
+                    selJ[R] = bi & 0xFF;
+                    selV[R] = bv;
+                    if (dup || (bi & 0x8000) || !(bv > NEG_INF_D)) sc[FS_BAD2] = 1;
+                }
+            }
+        };
+        if (!fail_ && wave != 0) {  // helpers: a merge pass whenever wavefront 0 calls one
+            for (;;) {
+                lds_barrier();
+                if (sc[FS_CMD] == CMD_DONE) break;
+                merge_pass(sc[FS_NNEW] >> 16);
+                lds_barrier();
+            }
+        }
+        if (!fail_ && wave == 0) {
+            double off[NPL], selVr[NPL];
+            int mycomp[NPL], selIr[NPL], selJr[NPL];
+            bool alive[NPL], isnew[NPL], settled[NPL];
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) {
+                const int v = lane + 64 * q;
+                alive[q] = v >= 1 && v < l;
+                mycomp[q] = v;
+                off[q] = 0.0;
+                selIr[q] = v;
+                selJr[q] = alive[q] ? bjL[v] : 0;
+                selVr[q] = alive[q] ? (double)bvL[v] : 0.0;
+                isnew[q] = false; settled[q] = false;
+            }
+            int rounds = 0;
+            for (;;) {
+                const int stamp = rounds + 1;
+                // heads of the components; flags: its path is known to reach ROOT / it was created in the last round
+                int hc[NPL];
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) hc[q] = alive[q] ? comp[selJr[q]] : 0;
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) {
+                    const int v = lane + 64 * q;
+                    if (v < l) hcAw[v] = alive[q] ? (hc[q] | (settled[q] ? HC_SETTLED : 0) | (isnew[q] ? HC_NEW : 0)) : HC_SETTLED;
+                }
+                if (lane == 0) sc[FS_NNEW] = 0;
+                WFENCE();
+                bool found[NPL];
+                int mn[NPL], clen[NPL], vis[kWalkMax][NPL];
+                double tot[NPL], vsv[kWalkMax][NPL];
+                bool allwalk = rounds == 0;
+                if (!allwalk) {
+                    // A new cycle passes through a component created in the last round: bounded walk from those.  A walk ends when it is back at its start (cycle); at a
+                    // component known to reach ROOT (so does this one); at another walker with a SMALLER index (if the two
+                    // share a cycle, the cycle's smallest walker goes all the way round and labels every member); or at a
+                    // node it has seen before (Brent's checkpoints: it circles a cycle it is not part of: once that one is contracted, whatever
+                    // cycle forms through here passes through the new component).
+                    int cur[NPL], chk[NPL];
+                    bool act[NPL];
+#pragma unroll
+                    for (int q = 0; q < NPL; ++q) {
+                        found[q] = false; act[q] = isnew[q]; cur[q] = hc[q]; chk[q] = -1;
+                        mn[q] = lane + 64 * q; tot[q] = selVr[q]; clen[q] = 1;
+#pragma unroll
+                        for (int s = 0; s < kWalkMax; ++s) { vis[s][q] = 0; vsv[s][q] = 0.0; }
+                    }
+#pragma unroll
+                    for (int s = 0; s <= kWalkMax; ++s) {  // unrolled: the components passed are kept in registers
+                        bool any = false;
+                        const bool mark = (s & (s - 1)) == 0;  // s = 0, 1, 2, 4: move the checkpoint (Brent)
+#pragma unroll
+                        for (int q = 0; q < NPL; ++q) {  // selects only: no control flow inside a step
+                            if (!__ballot(act[q])) continue;  // wave-uniform: no walker in this half
+                            const int self = lane + 64 * q;
+                            const bool hit = act[q] && cur[q] == self, atroot = act[q] && cur[q] == 0;
+                            const bool loop = act[q] && cur[q] == chk[q];  // circling a cycle this walker is not part of
+                            found[q] = found[q] || hit;
+                            settled[q] = settled[q] || atroot;
+                            act[q] = act[q] && !hit && !atroot && !loop;
+                            if (s == kWalkMax) { act[q] = false; continue; }  // out of steps: forgotten
+                            chk[q] = mark ? cur[q] : chk[q];
+                            const int at = act[q] ? cur[q] : 0;
+                            const int w = hcAw[at];
+                            const double sv = selV[at];
+                            const bool st = act[q] && (w & HC_SETTLED);
+                            const bool go = act[q] && !st && !((w & HC_NEW) && cur[q] < self);
+                            settled[q] = settled[q] || st;
+                            vis[s][q] = at; vsv[s][q] = sv;
+                            mn[q] = (go && cur[q] < mn[q]) ? cur[q] : mn[q];
+                            tot[q] = go ? tot[q] + sv : tot[q];
+                            clen[q] += go ? 1 : 0;
+                            cur[q] = go ? (w & HC_MASK) : cur[q];
+                            act[q] = go;
+                            any = any || go;
+                        }
+                        if (!__ballot(any)) break;
+                    }
+                    // Nothing found: either no cycle is left, or one is longer than the walk (or its new components all
+                    // stopped short); the full pass decides.  A walk that ran out of steps is simply forgotten: the cycle
+                    // it may be on stays where it is until a full pass sees it.
+                    bool anyf = false;
+#pragma unroll
+                    for (int q = 0; q < NPL; ++q) anyf = anyf || found[q];
+                    if (!__ballot(anyf)) allwalk = true;
+                }
+                if (allwalk) {
+                    // pointer doubling over all components: after >= l steps a pointer rests on its cycle, or on ROOT
+                    int word[NPL];
+#pragma unroll
+                    for (int q = 0; q < NPL; ++q) word[q] = alive[q] ? hc[q] : 0;
+                    for (int span = 1; span < l; span <<= 1) {
+                        int nw[NPL];
+#pragma unroll
+                        for (int q = 0; q < NPL; ++q) {
+                            const int tn = word[q];
+                            int y = __shfl(word[0], tn & 63);
+#pragma unroll
+                            for (int q2 = 1; q2 < NPL; ++q2) {
+                                const int y2 = __shfl(word[q2], tn & 63);
+                                if ((tn >> 6) == q2) y = y2;
+                            }
+                            nw[q] = y;
+                        }
+#pragma unroll
+                        for (int q = 0; q < NPL; ++q) word[q] = nw[q];
+                    }
+#pragma unroll
+                    for (int q = 0; q < NPL; ++q) {
+                        if (alive[q]) {
+                            if (word[q] != 0) cycf[word[q]] = -stamp;  // negative: "on a cycle", not yet labelled
+                            else settled[q] = true;
+                        }
+                    }
+                    WFENCE();
+                    int cur[NPL];
+                    bool act[NPL];
+#pragma unroll
+                    for (int q = 0; q < NPL; ++q) {
+                        const int v = lane + 64 * q;
+                        found[q] = alive[q] && cycf[v] == -stamp;
+                        act[q] = found[q]; cur[q] = hc[q]; mn[q] = v; tot[q] = selVr[q]; clen[q] = 1;
+                    }
+#pragma unroll 1
+                    for (;;) {  // every member walks its own cycle: smallest member, sum of the cycle's edges (:73-75)
+                        bool any = false;
+#pragma unroll
+                        for (int q = 0; q < NPL; ++q) {
+                            act[q] = act[q] && cur[q] != lane + 64 * q;
+                            const int at = act[q] ? cur[q] : 0;
+                            const int w = hcAw[at];
+                            const double sv = selV[at];
+                            mn[q] = (act[q] && cur[q] < mn[q]) ? cur[q] : mn[q];
+                            tot[q] = act[q] ? tot[q] + sv : tot[q];
+                            clen[q] += act[q] ? 1 : 0;
+                            cur[q] = act[q] ? (w & HC_MASK) : cur[q];
+                            any = any || act[q];
+                        }
+                        if (!__ballot(any)) break;
+                    }
+                }
+                STAMP(2);
+                FCOUNT(9, allwalk ? 1 : 0);
+                bool anyf = false;
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) anyf = anyf || found[q];
+                if (!__ballot(anyf)) break;  // no cycle left: the components' in-edges form the tree
+                if (rounds >= hist_cap) { fail_ = 1; break; }
+                // this round's record: components and in-edges BEFORE the merge
+                {
+                    unsigned char *hr = hist + (long)rounds * 3 * L;
+#pragma unroll
+                    for (int q = 0; q < NPL; ++q) {
+                        const int v = lane + 64 * q;
+                        if (v < l) {
+                            hr[v] = (unsigned char)mycomp[q];
+                            hr[L + v] = (unsigned char)selIr[q];
+                            hr[2 * L + v] = (unsigned char)selJr[q];
+                        }
+                    }
+                }
+                // Labels (smallest member) and row offsets total - e_m (:84) of every member of every cycle.  One lane per
+                // cycle also lists the members for the merge below: the walker that found it (it is the only one), or, after
+                // a full pass (every member walked), the member that is the label.
+                bool writer[NPL];
+                int woff[NPL];
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) {
+                    const int v = lane + 64 * q;
+                    writer[q] = found[q] && (!allwalk || mn[q] == v);
+                    woff[q] = 0;
+                    if (found[q]) {
+                        lab[v] = mn[q];
+                        dlt[v] = tot[q] - selVr[q];
+                        cycf[v] = stamp;
+                    }
+                    if (writer[q]) {
+                        const int x = atomicAdd(&sc[FS_NNEW], (1 << 16) | clen[q]);  // (cycles so far, members so far)
+                        woff[q] = x & 0xFFFF;
+                        newlist[x >> 16] = mn[q] | (woff[q] << 8) | (clen[q] << 16);
+                        pool[woff[q]] = v;
+                    }
+                }
+                if (!allwalk) {  // the finder passed every other member on its walk: labels, offsets, member list from registers
+#pragma unroll
+                    for (int q = 0; q < NPL; ++q) {
+                        if (!__ballot(found[q])) continue;
+#pragma unroll
+                        for (int s = 0; s < kWalkMax; ++s)
+                            if (found[q] && s < clen[q] - 1) {
+                                const int m = vis[s][q];
+                                lab[m] = mn[q];
+                                dlt[m] = tot[q] - vsv[s][q];
+                                cycf[m] = stamp;
+                                pool[woff[q] + 1 + s] = m;
+                            }
+                    }
+                } else {  // after a full pass every member has walked and labelled itself; the label lists the members
+                    int cur[NPL], k[NPL];
+                    bool act[NPL];
+#pragma unroll
+                    for (int q = 0; q < NPL; ++q) { act[q] = writer[q]; cur[q] = hc[q]; k[q] = 1; }
+#pragma unroll 1
+                    for (;;) {
+                        bool any = false;
+#pragma unroll
+                        for (int q = 0; q < NPL; ++q) {
+                            act[q] = act[q] && cur[q] != lane + 64 * q;
+                            const int at = act[q] ? cur[q] : 0;
+                            const int w = hcAw[at];
+                            if (act[q]) pool[woff[q] + k[q]] = at;
+                            k[q] += act[q] ? 1 : 0;
+                            cur[q] = act[q] ? (w & HC_MASK) : cur[q];
+                            any = any || act[q];
+                        }
+                        if (!__ballot(any)) break;
+                    }
+                }
+                WFENCE();
+                STAMP(3);
+                // every word of a merged component: new label, offset
+                bool merged[NPL];
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) {
+                    const int v = lane + 64 * q;
+                    const bool row = v >= 1 && v < l;
+                    const int c = row ? mycomp[q] : 0;
+                    const int cf = cycf[c], lb = lab[c], cfv = cycf[row ? v : 0], lbv = lab[row ? v : 0];
+                    const double dl = dlt[c];
+                    merged[q] = row && cf == stamp;
+                    off[q] = merged[q] ? off[q] + dl : off[q];
+                    mycomp[q] = merged[q] ? lb : mycomp[q];
+                    alive[q] = alive[q] && !(cfv == stamp && lbv != v);
+                }
+#pragma unroll
+                for (int q = 0; q < NPL; ++q)
+                    if (merged[q]) { comp[lane + 64 * q] = mycomp[q]; offL[lane + 64 * q] = off[q]; }
+                WFENCE();
+                STAMP(4);
+                // ---- the new components' contracted rows and in-edges: one component per wavefront, all four at work
+                lds_barrier();
+                merge_pass(sc[FS_NNEW] >> 16);
+                lds_barrier();
+                const int nnew = sc[FS_NNEW] >> 16;
+                const int bad = sc[FS_BAD2];
+                WFENCE();
+                STAMP(5);
+                FCOUNT(10, nnew);
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) {
+                    const int v = lane + 64 * q;
+                    isnew[q] = merged[q] && mycomp[q] == v;
+                    if (isnew[q]) {
+                        selIr[q] = selI[v]; selJr[q] = selJ[v]; selVr[q] = selV[v];
+                        settled[q] = false;
+                    }
+                }
+                if (bad) { fail_ = 1; break; }
+                ++rounds;
+                STAMP(6);
+                FCOUNT(8, 1);
+            }
+            if (lane == 0) sc[FS_CMD] = CMD_DONE;  // releases the helper wavefronts
+            lds_barrier();
+            if (!fail_) {
+                // ---- expansion: the real in-edge of every component, the rounds undone in reverse
+                {
+                    unsigned char *hr = hist + (long)rounds * 3 * L;
+#pragma unroll
+                    for (int q = 0; q < NPL; ++q) {
+                        const int v = lane + 64 * q;
+                        if (v < l) hr[v] = (unsigned char)mycomp[q];
+                    }
+                }
+                WFENCE();
+                int *curI = selI, *curJ = selJ, *nxtI = rI, *nxtJ = rJ;
+                for (int s = rounds - 1; s >= 0; --s) {
+                    const unsigned char *hs = hist + (long)s * 3 * L, *hn = hs + 3 * L;
+#pragma unroll
+                    for (int q = 0; q < NPL; ++q) {
+                        const int v = lane + 64 * q;
+                        if (v >= 1 && v < l && hs[v] == v) {  // a component of this state
+                            const int Y = hn[v];
+                            const int ri = curI[Y], rj = curJ[Y];
+                            const bool inside = hs[ri] == v;
+                            nxtI[v] = inside ? ri : (int)hs[L + v];
+                            nxtJ[v] = inside ? rj : (int)hs[2 * L + v];
+                        }
+                    }
+                    WFENCE();
+                    int *t1 = curI; curI = nxtI; nxtI = t1;
+                    int *t2 = curJ; curJ = nxtJ; nxtJ = t2;
+                }
+                int head[NPL];
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) {
+                    const int v = lane + 64 * q;
+                    head[q] = (v >= 1 && v < l) ? curJ[v] : 0;
+                }
+                STAMP(7);
+                FCOUNT(11, 1);
+                if (mode == 1) {
+                    // ---- single-root logic (ref :137-141): one child of ROOT -> done, else its children are candidates
+                    int nroot = 0;
+#pragma unroll
+                    for (int q = 0; q < NPL; ++q) {
+                        const int v = lane + 64 * q;
+                        const int isr = (v >= 1 && v < l && head[q] == 0) ? 1 : 0;
+                        const unsigned long long bal = __ballot(isr);
+                        if (isr) a.cand_root[(long)b * L + nroot + __popcll(bal & lt_mask)] = v;  // ascending
+                        nroot += __popcll(bal);
+                    }
+                    if (nroot == 1) {
+#pragma unroll
+                        for (int q = 0; q < NPL; ++q) {
+                            const int v = lane + 64 * q;
+                            if (v < l) hout[v] = head[q];
+                        }
+                        if (lane == 0) a.status[b] = PHONLP_MST_OK;
+                    } else if (nroot == 0) {
+                        fail_ = 1;  // cannot happen for a tree; left to the reference-order kernel
+                    } else if (lane == 0) {
+                        a.cand_n[b] = nroot;
+                        a.status[b] = PHONLP_MST_PENDING;
+                    }
+                } else {
+                    // ---- a candidate's score (ref :155-158): exact, so the order of the additions is free
+                    double s = 0.0;
+#pragma unroll
+                    for (int q = 0; q < NPL; ++q) {
+                        const int v = lane + 64 * q;
+                        if (v >= 1 && v < l && v != root) s += (double)W[v * pitch + head[q]];
+                    }
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+                    s += (double)W[root * pitch];
+                    if (s > best_score) {  // strict: the first best candidate of this slot (ascending) wins
+                        best_score = s;
+                        best_ci = ci;
+                        uint16_t *tr = a.cs_tree + ((long)b * CS + slot) * L;
+#pragma unroll
+                        for (int q = 0; q < NPL; ++q) {
+                            const int v = lane + 64 * q;
+                            if (v < l) tr[v] = (uint16_t)head[q];
+                        }
+                    }
+                }
+            }
+            if (lane == 0) sc[FS_FAIL] = fail_;
+        }
+        __syncthreads();
+        fail_ = sc[FS_FAIL];
+        __syncthreads();
+        if (fail_) { failed = 1; break; }
+    }
+#ifdef MST_STAMPS
+    if (tid == 0 && a.dbg)
+        for (int k = 0; k < 16; ++k) a.dbg[((long)(mode - 1) * a.B + blockIdx.x) * 16 + k] = stamp_acc[k];
+#endif
+    if (tid == 0) {
+        if (mode == 1) {
+            if (failed) {
+                a.status[b] = PHONLP_MST_FALLBACK;
+                a.fb_list[atomicAdd(&a.ctr[CT_FB], 1)] = b | (2 << 24);  // 2 = (U) or the round limit, unconstrained decode
+            }
+        } else {
+            const long qx = (long)b * CS + slot;
+            a.cs_score[qx] = failed ? NEG_INF_D : best_score;
+            a.cs_idx[qx] = failed ? -2 : best_ci;
+        }
+    }
+}
+
+// The winner among a pending sentence's slots (greatest score, lowest candidate number among equals = the
+// reference's strict '>' in candidate order, :159); a slot that could not decide sends the sentence to the fallback.
+__global__ void mst_fast_pick_kernel(MstArgs a) {
+    const int b = blockIdx.x, tid = threadIdx.x, L = a.L, R = a.cslots;
+    if (a.status[b] != PHONLP_MST_PENDING) return;
+    int l = a.sentlens[b];
+    if (l > L) l = L;
+    const int ns = a.cand_n[b] < R ? a.cand_n[b] : R;
+    double best = NEG_INF_D;
+    int bs = -1, bi = INT_MAX, bad = 0;
+    for (int s = 0; s < ns; ++s) {
+        const double sc = a.cs_score[(long)b * R + s];
+        const int ix = a.cs_idx[(long)b * R + s];
+        if (ix < 0) bad = 1;
+        else if (sc > best || (sc == best && ix < bi)) { best = sc; bs = s; bi = ix; }
+    }
+    if (bad || bs < 0) {
+        if (tid == 0) {
+            a.status[b] = PHONLP_MST_FALLBACK;
+            a.fb_list[atomicAdd(&a.ctr[CT_FB], 1)] = b | (3 << 24);  // 3 = a candidate decode
+        }
+        return;
+    }
+    for (int t = tid; t < l; t += blockDim.x) a.heads[(long)b * L + t] = a.cs_tree[((long)b * R + bs) * L + t];
+    if (tid == 0) a.status[b] = PHONLP_MST_OK;
+}
+
+size_t mst_fast_bytes(int B, int L) {
+    const size_t q = (size_t)B * kFastSlots;
+    return align_up((size_t)B * sizeof(int32_t), 256) + align_up(q * sizeof(double), 256) +
+           align_up(q * sizeof(int32_t), 256) + align_up(q * L * sizeof(uint16_t), 256);
+}
+void mst_fast_carve(MstArgs &a, void *base) {
+    char *p = (char *)base;
+    const size_t q = (size_t)a.B * kFastSlots;
+    a.fb_list = (int32_t *)p;  p += align_up((size_t)a.B * sizeof(int32_t), 256);
+    a.cs_score = (double *)p;  p += align_up(q * sizeof(double), 256);
+    a.cs_idx = (int32_t *)p;   p += align_up(q * sizeof(int32_t), 256);
+    a.cs_tree = (uint16_t *)p;
+    a.cslots = kFastSlots;
+}
+
+// phases 1-3; the caller has cleared a.ctr and runs the reference-order kernel over the fallback list afterwards
+int launch_mst_fast(MstArgs a, hipStream_t stream) {
+    const FastLayout f = fast_layout(a.L);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    static bool attr_set[64] = {false};
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+        if (hipFuncSetAttribute((const void *)mst_fast_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void *)mst_fast_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return fail(PHONLP_ERR_LAUNCH, "mst_one_root: cannot raise the dynamic LDS limit");
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    }
+    for (int mode = 1; mode <= 2; ++mode) {
+        a.mode = mode;
+        const dim3 grid(mode == 1 ? a.B : a.B * kFastSlots);
+        if (a.L <= 64) hipLaunchKernelGGL(mst_fast_kernel<1>, grid, dim3(256), f.total, stream, a, f.pitch, f.hist_cap);
+        else hipLaunchKernelGGL(mst_fast_kernel<2>, grid, dim3(256), f.total, stream, a, f.pitch, f.hist_cap);
+        const int rc = check_launch("mst_fast_kernel");
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(mst_fast_pick_kernel, dim3(a.B), dim3(128), 0, stream, a);
+    return check_launch("mst_fast_pick_kernel");
+}
+
+}  // namespace phonlp

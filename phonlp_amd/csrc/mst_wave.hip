@@ -22,10 +22,9 @@
 // queue in global memory and every workgroup, once its own sentence is decoded, pops candidates -- of any sentence --
 // until the queue is empty.  Each candidate's score and tree go to global scratch; the workgroup that finishes a
 // sentence's LAST candidate picks the winner in candidate order with strict '>' (ref :159), so the result does not
-// depend on who decoded what.  A workgroup with nothing to pop leaves (default), or -- up to max_waiters of them --
-// waits for late pushes, and then only while every workgroup of the grid has started (all of them are then resident
-// and finish their first decode without needing its CU); if some have not started yet it exits, so the grid always
-// drains.
+// depend on who decoded what.  A workgroup with nothing to pop and no own sentence left exits (waiting for late
+// pushes was measured and dropped: the waiters' LDS keeps other streams' GEMMs off their CUs), so the grid always
+// drains; whoever pushes candidates pops them itself if nobody else does.
 #include <type_traits>
 
 #include "mst.h"
@@ -35,7 +34,6 @@ namespace phonlp {
 #define WFENCE() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
 
 enum { WS_NEXT = 0, WS_DONE, WS_COUNT = 8 };
-enum { CT_STARTED = 0, CT_FIRST_DONE, CT_Q_TAIL, CT_Q_HEAD, CT_WAITERS, CT_COUNT = 8 };
 
 size_t mst_share_zero_bytes(int B, int L) { return align_up(((size_t)CT_COUNT + B + (size_t)B * L) * sizeof(int32_t), 256); }
 size_t mst_share_bytes(int B, int L) {
@@ -169,9 +167,12 @@ __global__ __launch_bounds__(256) void mst_wave_kernel(MstArgs a, int stack_cap)
     const int wg = blockIdx.x, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6, sub = lane & 15;
     const int L = a.L, pitch = a.pitch, Lw = (L + 3) >> 2;
+    // own sentences: wg, wg + gridDim.x, ... -- entries of the fallback list when there is one (mst_fast.hip sent them
+    // here), the sentences themselves otherwise
+    const int nown = a.fb_list ? ld_i32(&a.ctr[CT_FB]) : a.B;
+    int own_k = wg;
     if (tid == 0) atomicAdd(&a.ctr[CT_STARTED], 1);
-    int b = wg, slot = -1, root = -1;  // current task: sentence, candidate slot (-1 = the unconstrained decode)
-    bool waiting = false;              // thread 0: this workgroup has taken one of the waiter places
+    int b = 0, slot = -1, root = -1;  // current task: sentence, candidate slot (-1 = the unconstrained decode)
 #ifdef MST_STAMPS
     long long stamp_acc[16] = {0};
     long long stamp_t = clock64();
@@ -189,7 +190,50 @@ __global__ __launch_bounds__(256) void mst_wave_kernel(MstArgs a, int stack_cap)
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 #define SM(r, c) S[(long)(r) * pitch + (c)]
 
-    for (;;) {  // one task per trip: first this workgroup's own sentence, then candidates popped from the queue
+    for (;;) {  // one task per trip: a candidate popped from the shared queue if there is one, else the next own sentence
+        if (tid == 0) {
+            int code = -1;
+            for (;;) {
+                const int h = ld_i32(&a.ctr[CT_Q_HEAD]), t = ld_i32(&a.ctr[CT_Q_TAIL]);
+                if (h >= t) break;
+                if (atomicCAS(&a.ctr[CT_Q_HEAD], h, h + 1) == h) {
+                    int v;
+                    while ((v = ld_i32(&a.tasks[h])) == 0) __builtin_amdgcn_s_sleep(2);  // pusher is mid-store
+                    code = v - 1;
+                    break;
+                }
+            }
+            if (code < 0 && own_k < nown) code = -2 - own_k;
+            // Fallback list only (few sentences on a small grid: a sentence's candidates would otherwise all be decoded
+            // by the workgroup that owns it): with nothing to do, wait for candidates while some sentence's
+            // unconstrained decode is still running -- but only once every workgroup of the grid has started, i.e. all
+            // of them are resident and none needs this one's CU; otherwise leave, so the grid always drains.
+            if (code == -1 && a.fb_list) {
+                while (ld_i32(&a.ctr[CT_STARTED]) >= (int)gridDim.x && ld_i32(&a.ctr[CT_FIRST_DONE]) < nown) {
+                    __builtin_amdgcn_s_sleep(32);
+                    const int h = ld_i32(&a.ctr[CT_Q_HEAD]), t = ld_i32(&a.ctr[CT_Q_TAIL]);
+                    if (h < t) { code = INT_MIN; break; }  // something was pushed: go round again and pop it
+                }
+            }
+            __threadfence();
+            sc[WS_NEXT] = code;
+        }
+        __syncthreads();
+        const int code = sc[WS_NEXT];
+        __syncthreads();
+        if (code == -1) break;  // nothing queued, no own sentence left
+        if (code == INT_MIN) continue;
+        if (code <= -2) {
+            const int k = -2 - code;
+            b = a.fb_list ? (a.fb_list[k] & 0xFFFFFF) : k;
+            slot = -1;
+            root = -1;
+            own_k += gridDim.x;
+        } else {
+            b = code >> 8;
+            slot = code & 0xFF;
+            root = ld_i32(&a.cand_root[(long)b * L + slot]);
+        }
         int err = 0;
         int l = a.sentlens[b];
         if (l > L) l = L;
@@ -619,45 +663,10 @@ __global__ __launch_bounds__(256) void mst_wave_kernel(MstArgs a, int stack_cap)
         }
         __syncthreads();
         }  // !skip
-        // ---- next task (thread 0 decides for the workgroup)
-        if (tid == 0) {
-            if (slot < 0) {
-                __threadfence();  // this sentence's pushes before the count that tells waiters no more are coming
-                atomicAdd(&a.ctr[CT_FIRST_DONE], 1);
-            }
-            int code = -1;
-            for (;;) {
-                const int h = ld_i32(&a.ctr[CT_Q_HEAD]), t = ld_i32(&a.ctr[CT_Q_TAIL]);
-                if (h < t) {
-                    if (atomicCAS(&a.ctr[CT_Q_HEAD], h, h + 1) == h) {
-                        int v;
-                        while ((v = ld_i32(&a.tasks[h])) == 0) __builtin_amdgcn_s_sleep(2);  // pusher is mid-store
-                        code = v - 1;
-                        break;
-                    }
-                    continue;
-                }
-                if (ld_i32(&a.ctr[CT_STARTED]) < a.B) break;  // not every workgroup is resident: never wait
-                if (!waiting) {  // a waiter holds its CU's LDS against the GEMMs of other streams: bounded number
-                    if (atomicAdd(&a.ctr[CT_WAITERS], 1) >= a.max_waiters) break;
-                    waiting = true;
-                }
-                if (ld_i32(&a.ctr[CT_FIRST_DONE]) >= a.B) {   // no push can follow; look once more, then leave
-                    if (ld_i32(&a.ctr[CT_Q_HEAD]) < ld_i32(&a.ctr[CT_Q_TAIL])) continue;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(32);
-            }
-            __threadfence();
-            sc[WS_NEXT] = code;
+        if (slot < 0 && tid == 0) {
+            __threadfence();  // this sentence's pushes before the count that tells waiters no more are coming from it
+            atomicAdd(&a.ctr[CT_FIRST_DONE], 1);
         }
-        __syncthreads();
-        const int code = sc[WS_NEXT];
-        __syncthreads();
-        if (code < 0) break;
-        b = code >> 8;
-        slot = code & 0xFF;
-        root = ld_i32(&a.cand_root[(long)b * L + slot]);
     }
 #ifdef MST_STAMPS
     if (tid == 0 && a.dbg)
@@ -672,30 +681,32 @@ __global__ void mst_clear_kernel(int32_t *p, int n) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0;
 }
 
+// the queue, its counters, the fallback count and the per-sentence candidate counts start at zero in every call
+int launch_mst_clear(const MstArgs &a, hipStream_t stream) {
+    const int nz = (int)(mst_share_zero_bytes(a.B, a.L) / sizeof(int32_t));
+    hipLaunchKernelGGL(mst_clear_kernel, dim3(ceil_div(nz, 1024) < 64 ? ceil_div(nz, 1024) : 64), dim3(256), 0, stream, a.ctr, nz);
+    if (hipGetLastError() != hipSuccess) return fail(PHONLP_ERR_LAUNCH, "mst_one_root: cannot clear the candidate queue");
+    return PHONLP_OK;
+}
+
+// a.fb_list == NULL: one workgroup per sentence.  Otherwise the sentences of the fallback list (count in ctr[CT_FB], known
+// on the device only) on a grid of at most 64 workgroups, each taking entries wg, wg + grid, ...: none, normally.
 int launch_mst_wave(MstArgs a, hipStream_t stream) {
     const WaveLayout w = wave_layout(a.L);
-    static bool attr_set = false;
-    if (!attr_set) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    static bool attr_set[64] = {false};  // the attribute is per device
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
         if (hipFuncSetAttribute((const void *)mst_wave_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
             hipFuncSetAttribute((const void *)mst_wave_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
             hipFuncSetAttribute((const void *)mst_wave_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return fail(PHONLP_ERR_LAUNCH, "mst_one_root: cannot raise the dynamic LDS limit");
-        attr_set = true;
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    // Measured (B=256, L=128, tools/ab_waiters.sh): 0 waiters is best -- workgroups that pop whatever is queued when they
-    // finish and leave otherwise give 1.16 ms alone / 3.96 ms per bench step; 256 waiters 1.25 / 4.12 (the waiters'
-    // LDS keeps the GEMMs of the other streams off their CUs).
-    static const int waiters = getenv("PHONLP_MST_WAITERS") ? atoi(getenv("PHONLP_MST_WAITERS")) : 0;
-    a.max_waiters = waiters;
-    // the queue, its counters and the per-sentence candidate counts start at zero in every launch
-    {
-        const int nz = (int)(mst_share_zero_bytes(a.B, a.L) / sizeof(int32_t));
-        hipLaunchKernelGGL(mst_clear_kernel, dim3(ceil_div(nz, 1024) < 64 ? ceil_div(nz, 1024) : 64), dim3(256), 0, stream, a.ctr, nz);
-        if (hipGetLastError() != hipSuccess) return fail(PHONLP_ERR_LAUNCH, "mst_one_root: cannot clear the candidate queue");
-    }
-    if (a.L <= 64) hipLaunchKernelGGL(mst_wave_kernel<1>, dim3(a.B), dim3(256), w.total, stream, a, w.stack_cap);
-    else if (a.L <= 128) hipLaunchKernelGGL(mst_wave_kernel<2>, dim3(a.B), dim3(256), w.total, stream, a, w.stack_cap);
-    else hipLaunchKernelGGL(mst_wave_kernel<4>, dim3(a.B), dim3(256), w.total, stream, a, w.stack_cap);
+    const dim3 grid(a.fb_list ? (a.B < 64 ? a.B : 64) : a.B);
+    if (a.L <= 64) hipLaunchKernelGGL(mst_wave_kernel<1>, grid, dim3(256), w.total, stream, a, w.stack_cap);
+    else if (a.L <= 128) hipLaunchKernelGGL(mst_wave_kernel<2>, grid, dim3(256), w.total, stream, a, w.stack_cap);
+    else hipLaunchKernelGGL(mst_wave_kernel<4>, grid, dim3(256), w.total, stream, a, w.stack_cap);
     return check_launch("mst_wave_kernel");
 }
 

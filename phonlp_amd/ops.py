@@ -236,6 +236,35 @@ def mst_one_root(arc: Tensor, sentlens: Tensor) -> Tuple[Tensor, Tensor]:
     return heads, status
 
 
+def set_mst_fast_path(on: bool) -> None:
+    """A/B and test knob: False decodes every sentence with the reference-order kernel (include/phonlp_heads.h)."""
+    check(lib().phonlp_set_mst_fast_path(int(bool(on))), "set_mst_fast_path")
+
+
+def get_mst_fast_path() -> bool:
+    return bool(lib().phonlp_get_mst_fast_path())
+
+
+def mst_one_root_counted(arc: Tensor, sentlens: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+    """mst_one_root plus the number of sentences the round-based decode handed to the reference-order kernel
+    (int32 scalar tensor on the device; -1 when the round-based path does not apply to this L)."""
+    _need(arc, torch.float32, "arc")
+    _need(sentlens, torch.int32, "sentlens")
+    B, L, _ = arc.shape
+    dev = arc.device
+    heads = torch.empty((B, L), dtype=torch.int32, device=dev)
+    status = torch.empty((B,), dtype=torch.int32, device=dev)
+    nb = lib().phonlp_mst_ws_bytes(B, L)
+    ws = _ws(nb, dev)
+    check(lib().phonlp_mst_one_root(_p(arc), _p(sentlens), B, L, _p(heads), _p(status), _p(ws), nb, _stream()),
+          "phonlp_mst_one_root")
+    off = lib().phonlp_mst_fallback_counter_offset(B, L)
+    if off < 0 or not get_mst_fast_path():
+        return heads, status, torch.full((), -1, dtype=torch.int32, device=dev)
+    mst_one_root_counted.last_list = ws[lib().phonlp_mst_fallback_list_offset(B, L):][:4 * B].view(torch.int32)
+    return heads, status, ws[off:off + 4].view(torch.int32)[0].clone()
+
+
 @torch.library.custom_op("phonlp_amd::label_project", mutates_args=())
 def label_project(hidden: Tensor, W12: Tensor, b12: Tensor, Wbt: Tensor, H: int, O: int,
                   pad_sentlens: Optional[Tensor] = None, b12_pad: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:

@@ -240,12 +240,23 @@ def _run_mst(dev, mats, L):
         l = m.shape[0]
         arc[b, :l, :l] = m
         lens[b] = l
-    heads, status = ops.mst_one_root(torch.from_numpy(arc).to(dev), torch.from_numpy(lens).to(dev))
+    heads, status, nfb = ops.mst_one_root_counted(torch.from_numpy(arc).to(dev), torch.from_numpy(lens).to(dev))
     torch.cuda.synchronize()
+    _run_mst.fallbacks = int(nfb.item())
     return heads.cpu().numpy(), status.cpu().numpy()
 
 
-def test_mst_golden_bit_exact(dev, golden):
+@pytest.fixture(params=["rounds", "reference-order"])
+def mst_path(request):
+    """Both MST decoders: the round-based kernel (with its per-sentence fallback) and the reference-order kernel alone."""
+    from phonlp_amd import ops
+    was = ops.get_mst_fast_path()
+    ops.set_mst_fast_path(request.param == "rounds")
+    yield request.param
+    ops.set_mst_fast_path(was)
+
+
+def test_mst_golden_bit_exact(dev, golden, mst_path):
     z = golden("mst.npz")
     mats, want = [], []
     po = ph = 0
@@ -267,7 +278,7 @@ def test_mst_golden_bit_exact(dev, golden):
                                       # the two-phase form of the long-sentence kernel: many candidate roots per sentence
                                       # (more than its four slots: round-robin), all-ties integer matrices, pair cycles
                                       (12, 160, "rooty"), (6, 200, "ints"), (9, 170, "pairs")])
-def test_mst_random_vs_c_oracle(dev, B, L, kind):
+def test_mst_random_vs_c_oracle(dev, B, L, kind, mst_path):
     rng = np.random.default_rng(B * 3 + L)
     mats = []
     for b in range(B):
@@ -291,6 +302,11 @@ def test_mst_random_vs_c_oracle(dev, B, L, kind):
         want, rc = C.mst_one_root(m)
         assert rc == 0
         assert heads[b, :m.shape[0]].tolist() == want.tolist(), f"sentence {b} l={m.shape[0]}"
+    if mst_path == "rounds" and L <= 128:
+        # float log-probabilities take the round-based kernel (a few sentences may still fall back: a sentence of 2-3
+        # words whose scores tie, or sums that are not provably exact); all-ties integer matrices never do
+        nfb = _run_mst.fallbacks
+        assert (nfb >= B // 2) if kind == "ints" else (nfb <= B // 8), f"{nfb} of {B} sentences fell back"
 
 
 def test_mst_root_only_sentence_reports_no_tree(dev):

@@ -12,12 +12,30 @@ heads = TaskHeads(HeadWeights.from_state_dict(S.make_state_dict(), dev))
 enc_dep, _ = S.make_encoder_outputs(B, L)
 lens = torch.tensor([L] * B, dtype=torch.int32, device=dev)
 arc = heads.parser(enc_dep.to(dev), lens)["arc_logp"]
-dbg = torch.zeros(B, 16, dtype=torch.int64, device=dev)
+fast = os.environ.get("STAMP_FAST", "1") == "1"
+ops.set_mst_fast_path(fast)
+dbg = torch.zeros(B * 5 if fast else B, 16, dtype=torch.int64, device=dev)
 os.environ["PHONLP_MST_DBG"] = str(dbg.data_ptr())
 ops.mst_one_root(arc, lens); torch.cuda.synchronize()
 dbg.zero_()
 ops.mst_one_root(arc, lens); torch.cuda.synchronize()
 d = dbg.cpu().double()
+if fast:  # round-based kernel: phase 1 = rows [0, B), phase 2 = rows [B, 5B) (one per candidate slot)
+    names = ["load+exact", "argmax", "detect", "label+record", "relabel", "merge+in-edge", "new-state", "expand+tail"]
+    for ph, (lo, hi) in (("phase 1", (0, B)), ("phase 2", (B, 5 * B))):
+        x = d[lo:hi]
+        x = x[x[:, 11] > 0]
+        if not len(x):
+            continue
+        tot = x[:, :8].sum(1)
+        print(f"{ph}: {len(x)} workgroups decoded; decodes/wg mean {x[:,11].mean():.2f} max {int(x[:,11].max())}; rounds/decode mean "
+              f"{x[:,8].sum()/x[:,11].sum():.1f}; full-detect rounds {100*x[:,9].sum()/max(x[:,8].sum(),1):.0f}%; new components per round "
+              f"{x[:,10].sum()/max(x[:,8].sum(),1):.2f}; cycles/wg mean {tot.mean():.0f} max {tot.max():.0f}")
+        for k, n in enumerate(names):
+            per = "per round" if 2 <= k <= 6 else "per decode"
+            den = x[:, 8].sum() if 2 <= k <= 6 else x[:, 11].sum()
+            print(f"  {n:14s} share {100*x[:,k].sum()/tot.sum():5.1f}%   {per} {x[:,k].sum()/max(den,1):8.0f} cyc")
+    sys.exit(0)
 names = ["init", "argmax", "cycles", "lists", "edge+sum", "enter/leave+rec", "contract", "expand", "oneroot", "-", "-", "-", "rescan"]
 tot = d[:, :9].sum(1) + d[:, 12]
 print("rows rescanned per level: %.2f" % (d[:, 13].sum() / max(d[:, 10].sum(), 1)))
