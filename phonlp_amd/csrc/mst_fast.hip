@@ -67,7 +67,7 @@ static FastLayout fast_layout(int L) {
     f.pitch = (L + 47) / 64 * 64 + 16;  // smallest p >= L with p % 64 == 16: four consecutive rows hit disjoint banks
     f.off_d = (size_t)L * f.pitch * sizeof(float);
     f.off_a = f.off_d + (size_t)3 * L * sizeof(double);
-    f.off_i = f.off_a + align_up((size_t)L * L, 16);
+    f.off_i = f.off_a + align_up((size_t)L * ((L + 3) & ~3), 16);
     f.off_hist = f.off_i + ((size_t)kFastIntArrays * L + FS_COUNT) * sizeof(int);
     const long room = 160L * 1024 - (long)f.off_hist;
     long cap = room / (3L * L) - 1;
@@ -173,7 +173,8 @@ __global__ __launch_bounds__(256) void mst_fast_kernel(MstArgs a, int pitch, int
     double *selV = reinterpret_cast<double *>(smem_raw + (size_t)L * pitch * sizeof(float));
     double *dlt = selV + L, *offL = dlt + L;
     unsigned char *A = reinterpret_cast<unsigned char *>(offL + L);
-    int *comp = reinterpret_cast<int *>(A + align_up((size_t)L * L, 16));
+    const int LA = (L + 3) & ~3;  // row pitch of A
+    int *comp = reinterpret_cast<int *>(A + align_up((size_t)L * LA, 16));
     int *bjL = comp + L, *hcAw = bjL + L, *selI = hcAw + L, *selJ = selI + L, *lab = selJ + L, *cycf = lab + L;
     int *claim = cycf + L, *pool = claim + L, *newlist = pool + L, *rI = newlist + L, *rJ = rI + L;
     float *bvL = reinterpret_cast<float *>(rJ + L);
@@ -188,17 +189,17 @@ __global__ __launch_bounds__(256) void mst_fast_kernel(MstArgs a, int pitch, int
     __syncthreads();
     {
         int lo = INT_MAX, hi = INT_MIN, bad = 0;
-        for (int i0 = wave; i0 < l; i0 += 32) {
-            float vals[8][NPL];
+        for (int i0 = wave; i0 < l; i0 += 64) {  // sixteen rows' loads in flight per wavefront: the HBM / L2 latency is paid twice
+            float vals[16][NPL];
 #pragma unroll
-            for (int r = 0; r < 8; ++r)
+            for (int r = 0; r < 16; ++r)
 #pragma unroll
                 for (int q = 0; q < NPL; ++q) {
                     const int i = i0 + 4 * r, j = lane + 64 * q;
                     vals[r][q] = (i < l && j < l) ? arc[(long)i * L + j] : 0.f;
                 }
 #pragma unroll
-            for (int r = 0; r < 8; ++r)
+            for (int r = 0; r < 16; ++r)
 #pragma unroll
                 for (int q = 0; q < NPL; ++q) {
                     const int i = i0 + 4 * r, j = lane + 64 * q;
@@ -250,8 +251,8 @@ __global__ __launch_bounds__(256) void mst_fast_kernel(MstArgs a, int pitch, int
         // ---- whole workgroup: first arg-max of every row (ref :58), component state
         if (tid == 0) { sc[FS_FAIL] = 0; sc[FS_CMD] = CMD_GO; sc[FS_BAD2] = 0; }
         for (int t = tid; t < l; t += 256) { comp[t] = t; cycf[t] = 0; lab[t] = t; offL[t] = 0.0; }
-        for (int t = tid; t < l * (L / 4); t += 256) {  // A[X][j] = X: a word is its own component's only row
-            const int X = t / (L / 4);
+        for (int t = tid; t < l * (LA / 4); t += 256) {  // A[X][j] = X: a word is its own component's only row
+            const int X = t / (LA / 4);
             reinterpret_cast<unsigned *>(A)[t] = 0x01010101u * (unsigned)X;
         }
         __syncthreads();
@@ -294,8 +295,8 @@ __global__ __launch_bounds__(256) void mst_fast_kernel(MstArgs a, int pitch, int
 #pragma unroll
                     for (int q = 0; q < NPL; ++q) {
                         const int j = (lane + 64 * q < l) ? lane + 64 * q : 0;
-                        a0[q] = A[m0 * L + j];
-                        a1[q] = A[m1 * L + j];
+                        a0[q] = A[m0 * LA + j];
+                        a1[q] = A[m1 * LA + j];
                     }
                     float w0[NPL], w1[NPL];
                     double o0[NPL], o1[NPL];
@@ -324,7 +325,7 @@ __global__ __launch_bounds__(256) void mst_fast_kernel(MstArgs a, int pitch, int
 #pragma unroll
                 for (int q = 0; q < NPL; ++q) {
                     const int j = lane + 64 * q;
-                    if (j < l) A[R * L + j] = (unsigned char)ca[q];
+                    if (j < l) A[R * LA + j] = (unsigned char)ca[q];
                     const bool ok = j < l && ccol[q] != R && !(skip0 && j == 0);
                     const double v = ok ? cv[q] : NEG_INF_D;
                     const bool gt = v > bv, eq = ok && v == bv;
@@ -638,17 +639,32 @@ __global__ __launch_bounds__(256) void mst_fast_kernel(MstArgs a, int pitch, int
                 }
                 WFENCE();
                 int *curI = selI, *curJ = selJ, *nxtI = rI, *nxtJ = rJ;
+                int hc0[NPL], hy[NPL], hi_[NPL], hj_[NPL];  // this round's record for the lane's words, loaded one round ahead
+                auto load_record = [&](int s_) {
+                    const unsigned char *hs = hist + (long)s_ * 3 * L, *hn = hs + 3 * L;
+#pragma unroll
+                    for (int q = 0; q < NPL; ++q) {
+                        const int v = (lane + 64 * q < l) ? lane + 64 * q : 0;
+                        hc0[q] = hs[v]; hy[q] = hn[v]; hi_[q] = hs[L + v]; hj_[q] = hs[2 * L + v];
+                    }
+                };
+                if (rounds > 0) load_record(rounds - 1);
                 for (int s = rounds - 1; s >= 0; --s) {
-                    const unsigned char *hs = hist + (long)s * 3 * L, *hn = hs + 3 * L;
+                    const unsigned char *hs = hist + (long)s * 3 * L;
+                    int c0[NPL], y[NPL], si[NPL], sj[NPL], ri[NPL], rj[NPL];
+#pragma unroll
+                    for (int q = 0; q < NPL; ++q) {
+                        c0[q] = hc0[q]; y[q] = hy[q]; si[q] = hi_[q]; sj[q] = hj_[q];
+                        ri[q] = curI[y[q]]; rj[q] = curJ[y[q]];
+                    }
+                    if (s > 0) load_record(s - 1);
 #pragma unroll
                     for (int q = 0; q < NPL; ++q) {
                         const int v = lane + 64 * q;
-                        if (v >= 1 && v < l && hs[v] == v) {  // a component of this state
-                            const int Y = hn[v];
-                            const int ri = curI[Y], rj = curJ[Y];
-                            const bool inside = hs[ri] == v;
-                            nxtI[v] = inside ? ri : (int)hs[L + v];
-                            nxtJ[v] = inside ? rj : (int)hs[2 * L + v];
+                        const bool inside = hs[ri[q]] == v;
+                        if (v >= 1 && v < l && c0[q] == v) {  // a component of this state
+                            nxtI[v] = inside ? ri[q] : si[q];
+                            nxtJ[v] = inside ? rj[q] : sj[q];
                         }
                     }
                     WFENCE();

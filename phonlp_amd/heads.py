@@ -181,6 +181,21 @@ class TaskHeads:
 
     def __init__(self, weights: HeadWeights):
         self.w = weights
+        # A/B switches of annotate_batch, read ONCE here (never per batch); the defaults are the measured best and
+        # what the tests run
+        env = os.environ.get
+        self.cfg = {
+            "mst_prio": int(env("PHONLP_MST_PRIO", "0")),        # HIP stream priority of the MST stream (-1 = high)
+            "tag_prio": int(env("PHONLP_TAG_PRIO", "0")),        # ... of the tagger stream
+            "tagger_fused": env("PHONLP_TAGGER_FUSED", "1") == "1",  # 0: pos_head + ner_emission instead of tagger_head
+            "tagger_late": int(env("PHONLP_TAGGER_LATE", "1")),  # tagger chain start: 0 batch start, 1 arc-done, 2 behind label W1/W2
+            "pos_fold": env("PHONLP_POS_FOLD", "1") == "1",      # scorers read [enc ; pos_dis] (K = 792) instead of [enc ; pos_emb]
+            "rows4": env("PHONLP_ROWS4", "1") != "0",            # unfused form: T in the rows-by-4 layout
+            "ones_col": env("PHONLP_ONES_COL", "1") == "1",      # unfused form: X1's ones column as a per-column bias
+            # stage A fused with labels-at-heads behind the MST (T never reaches HBM): default since the round-based MST
+            "label_fused": env("PHONLP_LABEL_FUSED", "1") == "1",
+        }
+        self._side = None
 
     # ---- JointModel.tagger_forward after the gather (ref annotate_model.py:132-152)
     def tagger(self, enc: torch.Tensor, sentlens) -> Dict[str, torch.Tensor]:
@@ -285,11 +300,10 @@ class TaskHeads:
             return {"pos": tag["pos_pred"], "ner": ner, "heads": heads, "rels": rels, "mst_status": status}
         w = self.w
         main = torch.cuda.current_stream()
-        if not hasattr(self, "_side"):
-            # A/B switches: HIP stream priorities of the MST / tagger streams (0 = default, -1 = high)
-            mst_prio = int(os.environ.get("PHONLP_MST_PRIO", "0"))
-            tag_prio = int(os.environ.get("PHONLP_TAG_PRIO", "0"))
-            self._side = (torch.cuda.Stream(priority=tag_prio), torch.cuda.Stream(priority=mst_prio), torch.cuda.Stream())
+        cfg = self.cfg
+        if self._side is None:
+            self._side = (torch.cuda.Stream(priority=cfg["tag_prio"]), torch.cuda.Stream(priority=cfg["mst_prio"]),
+                          torch.cuda.Stream())
         s_tag, s_mst, s_fin = self._side
         lens_d = as_sentlens(sentlens_dep, enc_dep.device)
         lens_t = as_sentlens(sentlens_tag, enc_tag.device)
@@ -297,7 +311,7 @@ class TaskHeads:
         def run_tagger(after):
             s_tag.wait_event(after)
             with torch.cuda.stream(s_tag):
-                if os.environ.get("PHONLP_TAGGER_FUSED", "1") == "1":  # A/B switch: 0 = pos_head + ner_emission
+                if cfg["tagger_fused"]:
                     pos_pred, ner_logits, _ = ops.tagger_head(enc_tag.contiguous(), lens_t, w.tag_Whn, w.tag_bhn,
                                                               w.upos_clf_w, w.upos_clf_b, w.emb_ner, w.ner_w_emb, w.ner_b)
                     tag = {"pos_pred": pos_pred, "ner_logits": ner_logits}
@@ -310,11 +324,10 @@ class TaskHeads:
 
         # The tagger chain starts when the arc scores are done, beside the MST and stage A (measured: 3.64 vs 3.71 ms
         # per step); PHONLP_TAGGER_LATE=0 (A/B) starts it beside the parser's own POS head and arc GEMMs instead
-        tagger_late = os.environ.get("PHONLP_TAGGER_LATE", "1") == "1"
         split = ops.get_gemm_engine() == 2 and w.lab_Wbt_s is not None
-        # A/B ("2"): behind the label scorer's W1/W2 layer (engine 2 path only)
-        tagger_later = split and os.environ.get("PHONLP_TAGGER_LATE", "1") == "2"
-        tagger_late = tagger_late or os.environ.get("PHONLP_TAGGER_LATE", "1") == "2"
+        # A/B (2): behind the label scorer's W1/W2 layer (engine 2 path only)
+        tagger_later = split and cfg["tagger_late"] == 2
+        tagger_late = cfg["tagger_late"] >= 1
         if not tagger_late and not tagger_later:
             start = torch.cuda.Event()
             start.record(main)
@@ -326,7 +339,7 @@ class TaskHeads:
         arcW, labW = w.arc_W12f_s, w.lab_W12f_s
         if split:  # engine 2: the large layers run on split images; the POS head's tail writes feat as one directly
             emb = w.emb_dep
-            if w.arc_W12p_s is not None and os.environ.get("PHONLP_POS_FOLD", "1") == "1":  # A/B switch
+            if w.arc_W12p_s is not None and cfg["pos_fold"]:
                 # the embedding is folded into the scorers' weights: the "feat" image is [enc | tag probabilities]
                 emb, arcW, labW = w.emb_eye, w.arc_W12p_s, w.lab_W12p_s
                 D = enc_dep.shape[2] + emb.shape[1]
@@ -359,15 +372,15 @@ class TaskHeads:
                 w12_done = torch.cuda.Event()
                 w12_done.record(main)
                 tag, ner, tag_done = run_tagger(w12_done)
-            rows4 = os.environ.get("PHONLP_ROWS4", "1") != "0"  # A/B switch: row-major T
-            # Fused form (stage A after the MST with the labels-at-heads contraction in its epilogue, T never stored):
-            # off by default -- measured 4.33 vs 4.02 ms per step joined (the MST is then exposed on the critical path)
-            # and 3.9-4.0 vs 3.95-3.98 streaming
-            fused = os.environ.get("PHONLP_LABEL_FUSED", "0") == "1"
+            rows4 = cfg["rows4"]
+            # Fused form (stage A after the MST with the labels-at-heads contraction in its epilogue): T (1.8 GB at the
+            # headline size) is neither written nor read.  It needs the heads, so it waits for the MST -- affordable since
+            # the round-based decode (csrc/mst_fast.hip); the MST runs beside the label scorer's W1/W2 layer and split.
+            fused = cfg["label_fused"]
             if fused:
                 T = x1p  # stage A runs after the MST, inside label_at_heads_fused (T never reaches memory)
             elif rows4:
-                ones_col = w.lab_ones_col if os.environ.get("PHONLP_ONES_COL", "1") == "1" else None  # A/B switch
+                ones_col = w.lab_ones_col if cfg["ones_col"] else None
                 T = ops.label_stage_a_split(x1p, x1i, w.lab_Wbt_s[0], w.lab_Wbt_s[1], B, Ld, w.H, w.O, ones_col)  # T4
             else:
                 T = ops.linear_split(x1p, x1i, w.lab_Wbt_s[0], w.lab_Wbt_s[1], None, ops.kp(w.H), False, None, 0, None, 1)

@@ -274,6 +274,8 @@ def test_mst_golden_bit_exact(dev, golden, mst_path):
 
 
 @pytest.mark.parametrize("B,L,kind", [(256, 128, "randn"), (128, 128, "rooty"), (128, 100, "ints"), (64, 128, "pairs"),
+                                      # one word per lane / odd widths / tiny sentences on the round-based kernel
+                                      (64, 43, "randn"), (40, 64, "pairs"), (33, 17, "rooty"), (50, 5, "randn"), (70, 97, "randn"),
                                       (24, 160, "randn"), (8, 300, "randn"), (6, 512, "randn"),
                                       # the two-phase form of the long-sentence kernel: many candidate roots per sentence
                                       # (more than its four slots: round-robin), all-ties integer matrices, pair cycles
