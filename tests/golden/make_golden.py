@@ -516,6 +516,49 @@ def gen_dep_loss():
     save("dep_loss_small.npz", **arrs)
 
 
+# ---------------------------------------------------------------------------- F10 BASELINE config 1 at full head sizes
+def gen_config1():
+    """BASELINE config 1: the reference's annotate() (annotate_model.py:218-339) over all 100 sentences of
+    sample_data/input.txt at PhoBERT-base head sizes (E=768, H=400, TE=100) and sample_data's label-set sizes
+    (U=24, O=30, T=12), at several batch sizes.  The encoder is replaced by tests/stub_model.TableEncoder (seeded
+    tables) and the head parameters are overwritten from phonlp_amd.synthetic.make_state_dict (seeded), so the fixture
+    holds only the sentences and the reference's output files -- no weights."""
+    sys.modules.setdefault("gdown", types.ModuleType("gdown"))
+    if REF_ROOT not in sys.path:
+        sys.path.insert(0, REF_ROOT)
+    sys.path.insert(0, os.path.join(OUT, "..", ".."))
+    from transformers import RobertaConfig
+    from phonlp.annotate_model import JointModel
+    from tests.stub_model import CONFIG1, TableEncoder, ToyTokenizer as StubTok, config1_head_state, config1_vocab
+    c = CONFIG1
+    cfg = RobertaConfig(vocab_size=c["vocab_size"], hidden_size=c["E"], num_hidden_layers=1, num_attention_heads=12,
+                        intermediate_size=64, max_position_embeddings=258, pad_token_id=1, output_hidden_states=True)
+    args = {"tag_emb_dim": c["TE"], "deep_biaff_hidden_dim": c["H"], "dropout": 0.5, "word_dropout": 0.33,
+            "linearization": True, "distance": True}
+    model = JointModel(args, config1_vocab(), cfg, StubTok(c["vocab_size"])).eval()
+    model.phobert = TableEncoder(c["vocab_size"], c["E"], seed=c["enc_seed"])
+    missing, unexpected = model.load_state_dict(config1_head_state(), strict=False)
+    assert not unexpected and all(m.startswith(("phobert.", "drop_replacement")) for m in missing), (missing, unexpected)
+    model.eval()
+    with open(os.path.join(REF, "sample_data", "input.txt")) as f:
+        lines = [ln.strip() for ln in f if ln.strip()]
+    arrs = {"sent_text": np.asarray(lines), "batch_sizes": np.asarray([1, 8, 32, 100], dtype=np.int64)}
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        fin, fout = os.path.join(td, "in.txt"), os.path.join(td, "out.txt")
+        with open(fin, "w") as f:
+            f.write("\n".join(lines) + "\n")
+        for bs in arrs["batch_sizes"].tolist():
+            with torch.no_grad():
+                model.annotate(input_file=fin, output_file=fout, batch_size=bs)
+            arrs[f"out_bs{bs}"] = np.asarray(open(fout).read())
+            print(f"config 1, batch_size {bs}: {len(open(fout).read().splitlines())} lines")
+    for bs in arrs["batch_sizes"].tolist()[1:]:
+        a, b = str(arrs["out_bs1"]).splitlines(), str(arrs[f"out_bs{bs}"]).splitlines()
+        print(f"  reference output at batch_size {bs} vs 1: {sum(x != y for x, y in zip(a, b))} of {len(a)} lines differ")
+    save("config1_sample.npz", **arrs)
+
+
 # ---------------------------------------------------------------------------- F7 NER entity scoring
 def gen_ner_entities():
     """Runs the reference's own score_by_entity / decode_from_bioes (models/ner/scorer.py, ner/utils.py) on random
@@ -566,6 +609,10 @@ if __name__ == "__main__":
     if "--only-crf" in sys.argv:
         gen_crf()
         sys.exit(0)
+    if "--only-config1" in sys.argv:
+        torch.set_num_threads(8)
+        gen_config1()
+        sys.exit(0)
     if "--only-dep-loss" in sys.argv:
         gen_dep_loss()
         sys.exit(0)
@@ -579,3 +626,4 @@ if __name__ == "__main__":
     gen_ner_entities()
     gen_trainer()
     gen_dep_loss()
+    gen_config1()

@@ -105,3 +105,53 @@ class StubJointModel(nn.Module):
         first = _pad(fields[1])
         words = _pad(fields[2])
         return tokens, first, words.eq(0), sum(len(s) for s in fields[3]), orig_idx, [len(x) for x in fields[1]]
+
+
+class TableEncoder(nn.Module):
+    """Encoder stand-in for the full-size fixture (BASELINE config 1): last hidden state = token table row + position
+    table row, both drawn from a seeded CPU generator -- the same rows in the authoring container (plugged into the
+    reference's JointModel by tests/golden/make_golden.py) and on the GPU box, so the fixture stores no encoder."""
+
+    def __init__(self, vocab_size=2000, hidden=768, max_pos=512, seed=4321):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        self.tok = nn.Parameter(torch.randn(vocab_size, hidden, generator=g), requires_grad=False)
+        self.pos = nn.Parameter(torch.randn(max_pos, hidden, generator=g) * 0.5, requires_grad=False)
+
+    def forward(self, tokens, *a, **k):
+        h = self.tok[tokens] + self.pos[: tokens.shape[1]].unsqueeze(0)
+        return (h, None, (h,))  # the reference reads output[2][-1] (annotate_model.py:119,159)
+
+
+CONFIG1 = dict(E=768, TE=100, H=400, U=24, O=30, T=12, vocab_size=2000, head_seed=2024, enc_seed=4321)
+
+
+def config1_vocab():
+    c = CONFIG1
+    return {
+        "upos": ToyVocab([f"P{k}" for k in range(c["U"] - 4)]),
+        "deprel": ToyVocab([f"rel{k}" for k in range(c["O"] - 4)]),
+        "ner_tag": ToyVocab([f"N{k}" for k in range(c["T"] - 4)]),
+        "word": ToyVocab([]), "char": ToyVocab([]),
+    }
+
+
+def config1_head_state():
+    from phonlp_amd import synthetic as S
+    c = CONFIG1
+    return S.make_state_dict(c["E"], c["TE"], c["H"], c["U"], c["O"], c["T"], seed=c["head_seed"])
+
+
+class StubJointModelFull(StubJointModel):
+    """The stand-in at PhoBERT-base head sizes with sample_data's label-set sizes (E=768, H=400,
+    TE=100, U=24, O=30, T=12) and the table encoder: what tests/golden/config1_sample.npz was recorded with."""
+
+    def __init__(self):
+        nn.Module.__init__(self)
+        c = CONFIG1
+        self.phobert = TableEncoder(c["vocab_size"], c["E"], seed=c["enc_seed"])
+        self._heads = config1_head_state()
+        self.args = {"linearization": True, "distance": True}
+        self.vocab = config1_vocab()
+        self.tokenizer = ToyTokenizer(c["vocab_size"])
+        self.eval()
