@@ -84,6 +84,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--corpus", type=int, default=0, metavar="N",
+                    help="BASELINE config 4 instead of the headline line: walk a corpus of N synthetic sentences "
+                         "(L=128, batches of 256, distinct batches drawn on the device) sharded by batch over the ranks; "
+                         "--steps/--warmup are ignored")
     args = ap.parse_args()
 
     if os.environ.get("PHONLP_BENCH_DEBUG"):  # where is every rank after N seconds? (hang diagnosis)
@@ -131,6 +135,62 @@ def main():
     ner_vocab = ["<PAD>", "<UNK>", "<EMPTY>", "<ROOT>", "O", "B-PER", "I-PER", "B-LOC", "I-LOC"][:T]
     tag_kind, tag_type = (t.to(dev) for t in tag_tables(ner_vocab))
 
+    def all_reduce(t, op=None):
+        """RCCL all-reduce of a device tensor (in place); the rehearsal mode's gloo group reduces a host copy."""
+        kw = {} if op is None else {"op": op}
+        if rehearsal:
+            h = t.cpu()
+            dist.all_reduce(h, **kw)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, **kw)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.corpus > 0:
+        # ---- BASELINE config 4: the whole corpus once, batches rank, rank + world, ... on this rank (streaming form), the
+        # counts all-reduced at the end; the timed region holds the walk, the on-device batch generation and the collective
+        from phonlp_amd.corpus import SyntheticCorpus, walk
+        corpus = SyntheticCorpus(args.corpus, B, L, E, U, O, T, seed=777)
+        walk(heads, corpus, rank, world, dev, last=2 * world)  # warm-up: two batches per rank
+        fence()
+        t0 = time.perf_counter()
+        cnt, cnt_ent, nsent = walk(heads, corpus, rank, world, dev)
+        counts_all = torch.cat([cnt, cnt_ent])
+        if dist is not None:
+            all_reduce(counts_all)
+        fence()
+        elapsed = time.perf_counter() - t0
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        if dist is not None:
+            all_reduce(t, dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        if rank == 0:
+            c = counts_all.cpu().tolist()
+            assert c[0] == args.corpus and c[6] == 0, f"eval counts inconsistent: {c}"
+            print(json.dumps({
+                "metric": "sentences/sec through POS+NER+dep heads, corpus walk", "value": args.corpus / elapsed,
+                "unit": "sentences/s", "n_gpus": world, "steps": corpus.n_batches, "warmup": 2,
+                "ms_per_step": elapsed / ((corpus.n_batches + world - 1) // world) * 1e3, "higher_is_better": True,
+                "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": f"BASELINE config 4: {args.corpus} synthetic sentences L={L} in {corpus.n_batches} "
+                                       f"distinct batches of {B} drawn on the device, batch-sharded over {world} rank(s), "
+                                       "one all-reduce of the eval counts", "batch_per_gpu": B, "seq_len": L,
+                           "parallelism": f"sentence-sharded x{world}"},
+                "note": "the timed region includes generating every batch on the device (two randn of B x L x 768)",
+                "eval_counts": {"sentences": c[0], "words": c[1], "pos_correct": c[2], "ner_correct": c[3],
+                                "uas_correct": c[4], "las_correct": c[5], "ner_entities_correct": c[8],
+                                "ner_entities_predicted": c[9], "ner_entities_gold": c[10]},
+            }), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
     STREAMING = int(os.environ.get("PHONLP_BENCH_STREAMING", "0"))
     COUNTS_INLINE = os.environ.get("PHONLP_BENCH_COUNTS_INLINE", "0") == "1"
     s_cnt = torch.cuda.Stream()
@@ -157,22 +217,6 @@ def main():
                 ops.eval_counts_into(counts, out["pos"], out["ner"], out["heads"], out["rels"], gold_pos, gold_ner,
                                      gold_head, gold_rel, lt, ld, out["mst_status"])
         return out
-
-    def all_reduce(t, op=None):
-        """RCCL all-reduce of a device tensor (in place); the rehearsal mode's gloo group reduces a host copy."""
-        kw = {} if op is None else {"op": op}
-        if rehearsal:
-            h = t.cpu()
-            dist.all_reduce(h, **kw)
-            t.copy_(h)
-        else:
-            dist.all_reduce(t, **kw)
-
-    def fence():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     engine = ops.get_gemm_engine()
     other_ms = {}

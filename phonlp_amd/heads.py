@@ -310,6 +310,8 @@ class TaskHeads:
         # tagger chain on its own stream
         def run_tagger(after):
             s_tag.wait_event(after)
+            for t in (enc_tag, lens_t):  # the caller may drop its batch while the side stream still reads it
+                t.record_stream(s_tag)
             with torch.cuda.stream(s_tag):
                 if cfg["tagger_fused"]:
                     pos_pred, ner_logits, _ = ops.tagger_head(enc_tag.contiguous(), lens_t, w.tag_Whn, w.tag_bhn,
@@ -360,6 +362,7 @@ class TaskHeads:
         # MST beside the label scorer
         s_mst.wait_event(arc_done)
         arc_logp.record_stream(s_mst)
+        lens_d.record_stream(s_mst)
         with torch.cuda.stream(s_mst):
             heads, status = ops.mst_one_root(arc_logp, lens_d)
             mst_done = torch.cuda.Event()
