@@ -340,6 +340,43 @@ def test_deep_biaffine_golden(dev, engine, golden):
             _close(raw[0], ref.squeeze(3), rtol=1e-4, atol=1e-5)
 
 
+def test_pairwise_bilinear_golden_on_gpu(dev, engine, golden):
+    """The PairwiseBilinear fixtures (reference output for raw x1 != x2, O up to 33, non-zero bias that the reference
+    never adds, biaffine.py:21-37) through phonlp_deep_biaffine_label.  The entry point takes ONE hidden tensor and
+    ReLU'd first layers, so a signed pair (x1, x2) goes in as four non-negative problems -- hidden = [x1+- | x2+-], W1 /
+    W2 selecting the halves, zero biases -- combined by bilinearity; the weight is laid out so that the pack's flat
+    reshape (the reference's quirk) lands on the fixture's effective weight."""
+    from phonlp_amd import ops
+    z = golden("biaffine.npz")
+    for c in range(int(z["n_pb"])):
+        x1, x2 = torch.from_numpy(z[f"pb{c}_x1"]), torch.from_numpy(z[f"pb{c}_x2"])
+        w, ref = torch.from_numpy(z[f"pb{c}_weight"]), torch.from_numpy(z[f"pb{c}_out"])  # ref: B x L1 x L2 x O
+        assert float(np.abs(z[f"pb{c}_bias"]).max()) > 0  # the fixture's bias is non-zero and must not show up
+        B, L1, D1 = x1.shape
+        _, L2, D2 = x2.shape
+        Ow = w.shape[2]
+        H, L = max(D1, D2), max(L1, L2)
+        eff = w.reshape(D1, Ow, D2)  # what the reference's view() makes of the stored (D1, D2, O) weight
+        big = torch.zeros(H + 1, Ow, H + 1)
+        big[:D1, :, :D2] = eff
+        wbig = big.reshape(H + 1, H + 1, Ow).contiguous()  # flat memory = [d1][o][d2]: the pack reads it back that way
+        D = 2 * H
+        Dp = (D + 3) // 4 * 4
+        W1 = torch.zeros(H, Dp); W1[:, :H] = torch.eye(H)
+        W2 = torch.zeros(H, Dp); W2[:, H:2 * H] = torch.eye(H)
+        W12, b12, Wbt = ops.pack_scorer(W1.to(dev), torch.zeros(H).to(dev), W2.to(dev), torch.zeros(H).to(dev), wbig.to(dev))
+        total = torch.zeros(B, L, Ow, L)
+        for s1 in (1.0, -1.0):
+            for s2 in (1.0, -1.0):
+                hid = torch.zeros(B, L, Dp)
+                hid[:, :L1, :D1] = torch.relu(s1 * x1)
+                hid[:, :L2, H:H + D2] = torch.relu(s2 * x2)
+                _, sc = ops.deep_biaffine_label(hid.contiguous().to(dev), W12, b12, Wbt, H, Ow, True)
+                total += s1 * s2 * sc.cpu()
+        got = total.permute(0, 1, 3, 2)[:, :L1, :L2]
+        _close(got, ref, rtol=2e-4, atol=2e-4 * float(ref.abs().max()))
+
+
 # ------------------------------------------------------------------------------------------ whole head path
 @pytest.mark.parametrize("name", ["joint_small.npz", "joint_zero_init.npz"])
 def test_joint_fixture_end_to_end(dev, engine, golden, name):
@@ -497,15 +534,22 @@ def test_scorer_flags(dev, engine, lin, dist):
     assert np.array_equal(out["rels"].cpu().numpy(), rel)
 
 
-def test_headline_batch_properties(dev, engine):
-    """B=256, L=128 (BASELINE config 3): sentences are independent, so any sub-batch must reproduce the big
-    batch bit-for-bit; decoded trees must be single-rooted and acyclic; decoders match the C oracle."""
-    from phonlp_amd import HeadWeights, TaskHeads
+HEADLINE_RATES = {}  # (engine, ragged) -> measured rates, printed by the test (DESIGN.md quotes them)
+
+
+@pytest.mark.parametrize("ragged", [False, True], ids=["full", "ragged"])
+def test_headline_batch_properties(dev, engine, ragged):
+    """B=256, L=128 (BASELINE config 3; `ragged`: lengths uniform in [32, 128], sorted descending): sentences are
+    independent, so any sub-batch must reproduce the big batch bit-for-bit; decoded trees must be single-rooted and
+    acyclic; decoders match the C oracle on the GPU's scores; and for 16 of the 256 sentences the arc log-probs, the
+    winning label scores, the NER emissions and every decoded id are compared with the CPU oracle (sub-batch identity
+    makes 16 sentences stand for the batch)."""
+    from phonlp_amd import HeadWeights, TaskHeads, ops
     from phonlp_amd import synthetic as S
     B, L = 256, 128
     sd = S.make_state_dict()
     enc_dep, enc_tag = S.make_encoder_outputs(B, L)
-    lens1 = S.make_sentlens(B, L, False)
+    lens1 = S.make_sentlens(B, L, ragged)
     lens = [l - 1 for l in lens1]
     heads = TaskHeads(HeadWeights.from_state_dict(sd, dev))
     big = heads.annotate_batch(enc_dep.to(dev), lens1, enc_tag.to(dev), lens)
@@ -517,8 +561,9 @@ def test_headline_batch_properties(dev, engine):
     assert (big["mst_status"] == 0).all()
     h = big["heads"].cpu().numpy()
     for b in range(B):
-        assert (h[b, 1:] == 0).sum() == 1  # exactly one child of ROOT
-        for i in range(1, L):  # every node reaches ROOT
+        assert (h[b, 1:lens1[b]] == 0).sum() == 1  # exactly one child of ROOT
+        assert not h[b, lens1[b]:].any()
+        for i in range(1, lens1[b]):  # every node reaches ROOT
             v, steps = i, 0
             while v != 0 and steps <= L:
                 v, steps = h[b, v], steps + 1
@@ -527,7 +572,40 @@ def test_headline_batch_properties(dev, engine):
     assert np.array_equal(h, wh)
     rel_want = np.take_along_axis(dep["label_argmax"].cpu().numpy(), h[:, :, None].astype(np.int64), 2)[:, :, 0]
     rel_want[:, 0] = 0
+    for b in range(B):
+        rel_want[b, lens1[b]:] = 0
     assert np.array_equal(big["rels"].cpu().numpy(), rel_want)
+    # ---- 16 sentences against the CPU oracle: scores within the north star's 1e-3 relative (tighter here), ids exact
+    sl1, sl = lens1[sub], lens[sub]
+    od = O.dep_heads(enc_dep[sub], sl1, sd, keep_label_scores=True)
+    ot = O.tagger_heads(enc_tag[sub], sl, sd)
+    _close(dep["arc_logp"][sub], od["arc_logp"], rtol=2e-4, atol=2e-5)
+    tag = heads.tagger(enc_tag[sub].to(dev), sl)
+    _close(tag["ner_logits"], ot["ner_logits"], rtol=2e-4, atol=2e-5)
+    assert torch.equal(tag["pos_pred"].cpu().long(), ot["pos_pred"])
+    XF, T = ops.label_project(dep["hidden_out"][sub].contiguous(), heads.w.lab_W12, heads.w.lab_b12, heads.w.lab_Wbt,
+                              heads.w.H, heads.w.O)
+    hs = big["heads"][sub].contiguous()
+    _, best = ops.label_at_heads(T, XF, hs, torch.tensor(sl1, dtype=torch.int32, device=dev), heads.w.H, heads.w.O)
+    lab = od["label_scores"]  # [b, i, j, o]
+    n_words = n_head = n_rel = n_ner = 0
+    want_h, want_st = C.mst_batch(od["arc_logp"].numpy(), sl1)
+    want_t, _ = C.viterbi_batch(ot["ner_logits"].numpy(), sd["crit_ner._transitions"].numpy(), sl)
+    assert not want_st.any()
+    hg, rg, ng = hs.cpu().numpy(), big["rels"][sub].cpu().numpy(), big["ner"][sub].cpu().numpy()
+    for b in range(16):
+        for i in range(1, sl1[b]):
+            n_words += 1
+            row = lab[b, i, hg[b, i]]
+            assert abs(float(best.view(16, L)[b, i]) - float(row.max())) <= 2e-4 * max(1.0, abs(float(row.max())))
+            n_head += int(hg[b, i] != want_h[b, i])
+            if hg[b, i] == want_h[b, i]:
+                n_rel += int(rg[b, i] != int(row.argmax()))
+        n_ner += int((ng[b, :sl[b]] != want_t[b, :sl[b]]).sum())
+    HEADLINE_RATES[(engine, ragged)] = (n_words, n_head, n_rel, n_ner)
+    print(f"headline parity vs oracle, engine {engine}, ragged {ragged}: {n_words} words; differing heads {n_head}, "
+          f"relations {n_rel}, NER tags {n_ner}")
+    assert n_head == 0 and n_rel == 0 and n_ner == 0
 
 
 def test_long_sentence_batch_properties(dev):
