@@ -459,7 +459,7 @@ def test_synthetic_heads_vs_oracle(dev, engine, B, L, ragged):
     _close(dep["arc_logp"], od["arc_logp"], rtol=1e-3, atol=1e-4)
     _close(dep["label_scores"].permute(0, 1, 3, 2), od["label_scores"], rtol=1e-3, atol=1e-4)
     flips = _near_tie_ok(dep["label_argmax"].cpu(), od["label_argmax"], od["label_scores"], 1e-4)
-    assert flips <= 1e-4 * B * L * L
+    assert flips == 0  # near-ties would be tolerated by _near_tie_ok; none occurs on these inputs (printed below)
     _close(tag["ner_logits"], ot["ner_logits"], rtol=1e-4, atol=1e-5)
     _near_tie_ok(tag["pos_pred"].cpu(), ot["pos_pred"], ot["upos_logits"], 1e-5)
     # decoders are bit-exact GIVEN the same scores: feed the GPU decoders the GPU scores and compare with
@@ -472,7 +472,10 @@ def test_synthetic_heads_vs_oracle(dev, engine, B, L, ragged):
     assert np.array_equal(st.cpu().numpy(), ws) and np.array_equal(h.cpu().numpy(), wh)
     # and end-to-end: trees decoded from GPU scores vs trees decoded from oracle scores
     oh, _ = C.mst_batch(od["arc_logp"].numpy(), lens1)
-    assert (h.cpu().numpy() != oh).mean() <= 0.002
+    nh = int((h.cpu().numpy() != oh).sum())
+    print(f"synthetic heads vs oracle, engine {engine}, B={B} L={L} ragged={ragged}: label arg-max flips at near-ties "
+          f"{flips} of {B * L * L} dense cells; heads differing from the oracle-score trees {nh} of {sum(lens1) - B} words")
+    assert nh == 0  # bit-exact end to end on these inputs; the measured count is printed (DESIGN.md section 2 quotes it)
 
 
 @pytest.mark.parametrize("B,L,lens1", [(1, 2, [2]), (1, 3, [3]), (2, 5, [5, 2]), (5, 9, [9, 7, 4, 2, 2]),
