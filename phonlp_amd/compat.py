@@ -111,6 +111,9 @@ class PosCrossEntropy(nn.Module):
         dev = _dev()
         x = logits.to(dev, torch.float32).contiguous().unsqueeze(0)
         t = target.to(dev, torch.int32).contiguous().view(1, -1)
+        # nn.CrossEntropyLoss raises on a target outside [0, U); the kernel would skip it silently (costs one sync)
+        if bool(((t != self.ignore_index) & ((t < 0) | (t >= x.shape[-1]))).any()):
+            raise IndexError(f"PosCrossEntropy: target out of range for {x.shape[-1]} classes")
         lens = torch.tensor([x.shape[1]], dtype=torch.int32, device=dev)
         return _PosCE.apply(x, t, lens, self.ignore_index)
 
@@ -147,6 +150,33 @@ class DeepBiaffineScorer(nn.Module):
 
 
 # ---------------------------------------------------------------------------------------------------
+def _head_state(model):
+    return {k: v for k, v in model.state_dict().items() if not k.startswith("phobert.")}
+
+
+def _fingerprint(sd):
+    # in-place updates (optimizer steps, load_state_dict) bump a tensor's version counter; a replaced tensor has
+    # another address
+    return tuple((k, v._version, v.data_ptr()) for k, v in sd.items())
+
+
+def refresh_heads(model, device=None, force=False):
+    """(Re)packs the head weights of a patched model if any head parameter changed since the last pack -- the packs
+    (scorer images, float64 folds, split images) are COPIES, so a training step or load_state_dict after patch() /
+    patch_trainer() would otherwise leave the HIP path on stale weights.  Called on entry by every patched seam; costs
+    one pass over ~35 tensors' version counters when nothing changed, a full re-pack (tens of ms) when something did."""
+    sd = _head_state(model)
+    fp = _fingerprint(sd)
+    if force or getattr(model, "_amd_fingerprint", None) != fp:
+        dev = device or getattr(model, "_amd_device", None) or _dev()
+        weights = HeadWeights.from_state_dict(sd, dev, linearization=bool(model.args.get("linearization", True)),
+                                              distance=bool(model.args.get("distance", True)))
+        model._amd_heads = TaskHeads(weights)
+        model._amd_device = dev
+        model._amd_fingerprint = _fingerprint(_head_state(model))
+    return model._amd_heads
+
+
 def _encode(model, tokens, first_subword):
     """The part of the path that stays on PyTorch-ROCm: encoder + first-sub-word gather
     (ref annotate_model.py:119-123 / :159-163), as one batched gather instead of a Python loop."""
@@ -158,13 +188,13 @@ def _encode(model, tokens, first_subword):
 
 def _tagger_forward(self, tokens_phobert, words_phobert, sentlens):
     """ref annotate_model.py:113-152 -> ([LongTensor B x L], FloatTensor B x L x T)."""
-    out = self._amd_heads.tagger(_encode(self, tokens_phobert, words_phobert), sentlens)
+    out = refresh_heads(self).tagger(_encode(self, tokens_phobert, words_phobert), sentlens)
     return [out["pos_pred"].long()], out["ner_logits"]
 
 
 def _dep_forward(self, tokens_phobert, first_subword, sentlens):
     """ref annotate_model.py:154-216 -> [np.float32 B x L x L log-probs, np.int64 B x L x L label arg-max]."""
-    out = self._amd_heads.parser(_encode(self, tokens_phobert, first_subword), sentlens)
+    out = refresh_heads(self).parser(_encode(self, tokens_phobert, first_subword), sentlens)
     return [out["arc_logp"].cpu().numpy(), out["label_argmax"].cpu().numpy().astype(np.int64)]
 
 
@@ -181,6 +211,7 @@ def _annotate(self, text=None, input_file=None, output_file=None, batch_size=1, 
     parser_batches = self.chunk_batches(self.process_data_parser(batch_text=data), batch_size)
     tagger_batches = self.chunk_batches(self.process_data_tagger(batch_text=data), batch_size)
     pos_all, ner_all, dep_all = [], [], []
+    refresh_heads(self)
     with torch.no_grad():
         for i in range(len(tagger_batches)):
             tok, fsw, _, _, oidx, lens = self.get_batch(i, tagger_batches)
@@ -220,7 +251,8 @@ def _predict_dep(self, batch, unsort=True):
     """ref models/jointmodel/trainer.py:101-129 (over jointmodel/model.py:162-239 with eval=True): same batch tuple,
     same return value -- per sentence a list of [head string, deprel string] per word."""
     tokens, first_subword, orig_idx, sentlens = batch[0], batch[1], batch[6], batch[7]
-    h = self.model._amd_heads
+    self.model.eval()  # as the reference (trainer.py:104): update() leaves the model in train mode
+    h = refresh_heads(self.model)
     with torch.no_grad():
         dep = h.parser(_encode(self.model, tokens, first_subword), sentlens, want_label_argmax=False)
         heads, status = ops.mst_one_root(dep["arc_logp"], dep["sentlens"])
@@ -237,7 +269,8 @@ def _predict_dep(self, batch, unsort=True):
 def _predict_pos(self, batch, unsort=True):
     """ref trainer.py:131-144 (over jointmodel/model.py:107-137): per sentence a list of [upos string] per word."""
     tokens, first_subword, orig_idx, sentlens = batch[0], batch[1], batch[3], batch[4]
-    h = self.model._amd_heads
+    self.model.eval()  # trainer.py:134
+    h = refresh_heads(self.model)
     with torch.no_grad():
         enc = _encode(self.model, tokens, first_subword)
         lens = as_sentlens(sentlens, enc.device)
@@ -250,7 +283,8 @@ def _predict_pos(self, batch, unsort=True):
 def _predict_ner(self, batch, unsort=True):
     """ref trainer.py:146-166 (over jointmodel/model.py:139-160 + crf.py:103-126): per sentence a list of tag strings."""
     tokens, first_subword, orig_idx, sentlens = batch[0], batch[1], batch[4], batch[5]
-    h = self.model._amd_heads
+    self.model.eval()  # trainer.py:150
+    h = refresh_heads(self.model)
     with torch.no_grad():
         tag = h.tagger(_encode(self.model, tokens, first_subword), sentlens)
         ner, _ = ops.crf_viterbi(tag["ner_logits"], h.w.trans, tag["sentlens"])
@@ -262,8 +296,10 @@ def _predict_ner(self, batch, unsort=True):
 def _dev_loss(self, batch_dep=None, batch_pos=None, batch_ner=None, lambda_pos=1.0, lambda_ner=1.0, lambda_dep=1.0):
     """The forward half of ref trainer.py:62-99 (`update`, over jointmodel/model.py:243-281) with every dropout off
     and no backward: same batches and lambdas, same return order -- (loss, loss_pos, loss_ner, loss_dep) as floats.
-    For dev-loss monitoring; the kernels carry no autograd."""
-    h = self.model._amd_heads
+    For dev-loss monitoring; the kernels carry no autograd.  Puts the model in eval mode (every dropout off, the
+    encoder's included), like the reference's predict_* seams."""
+    self.model.eval()
+    h = refresh_heads(self.model)
     with torch.no_grad():
         tok, fsw, _, head, rel, nwords, _, lens = batch_dep[:8]
         l_dep = h.parser_loss(_encode(self.model, tok, fsw), lens, head, rel, nwords)[4]
@@ -281,15 +317,13 @@ def patch_trainer(trainer, device=None, move_encoder=True):
     """The evaluation-loop twin of patch(): rebinds `predict_dep`, `predict_pos` and `predict_ner` of a reference
     `JointTrainer` (models/jointmodel/trainer.py) so that the dev/test scoring loops of the training script run the
     heads and decoders on the MI355X, and adds `dev_loss` (the loss values of `update` on held-out batches).  `trainer.model` (jointmodel/model.py JointModel) keeps its encoder and its
-    training-mode forward; only the eval-mode seams change."""
+    training-mode forward; only the eval-mode seams change.  The seams follow the live parameters: they re-pack the
+    head weights (refresh_heads) when an optimizer step or load_state_dict changed them since the last call."""
     dev = device or _dev()
     model = trainer.model
     if move_encoder:
         model.phobert.to(dev)
-    sd = {k: v for k, v in model.state_dict().items() if not k.startswith("phobert.")}
-    weights = HeadWeights.from_state_dict(sd, dev, linearization=bool(model.args.get("linearization", True)),
-                                          distance=bool(model.args.get("distance", True)))
-    model._amd_heads = TaskHeads(weights)
+    refresh_heads(model, dev, force=True)  # re-packed by the seams themselves whenever a head parameter changes
     trainer.predict_dep = types.MethodType(_predict_dep, trainer)
     trainer.predict_pos = types.MethodType(_predict_pos, trainer)
     trainer.predict_ner = types.MethodType(_predict_ner, trainer)
@@ -314,10 +348,7 @@ def patch(model, device=None, move_encoder=True):
     dev = device or _dev()
     if move_encoder:
         model.phobert.to(dev)
-    sd = {k: v for k, v in model.state_dict().items() if not k.startswith("phobert.")}
-    weights = HeadWeights.from_state_dict(sd, dev, linearization=bool(model.args.get("linearization", True)),
-                                          distance=bool(model.args.get("distance", True)))
-    model._amd_heads = TaskHeads(weights)
+    refresh_heads(model, dev, force=True)
     model.tagger_forward = types.MethodType(_tagger_forward, model)
     model.dep_forward = types.MethodType(_dep_forward, model)
     model.annotate = types.MethodType(_annotate, model)

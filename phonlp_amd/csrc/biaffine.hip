@@ -595,15 +595,16 @@ static int arc_from_features(const float *XF, float *T, int B, int L, int KP, in
     ArcArgs a{T, XF, arc_logp, raw_opt, (long)S * KP, (long)S * 2 * KP, B, L, KP, S, 0, use_lin, use_dist};
     a.LP = (L + 31) / 32 * 32 + 1;
     const size_t lds = (size_t)(160 * PITCH + 32 * a.LP) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_once;
+    int attr_dev;
+    if (attr_once.pending(&attr_dev)) {
         const void *fns[] = {(const void *)arc_kernel<0>, (const void *)arc_kernel<1>, (const void *)arc_kernel128<0, 128>,
                              (const void *)arc_kernel128<1, 128>, (const void *)arc_kernel128<0, 64>,
                              (const void *)arc_kernel128<1, 64>};
         for (const void *f : fns)
             if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
                 return fail(PHONLP_ERR_LAUNCH, "deep_biaffine_arc: cannot raise the dynamic LDS limit");
-        attr_set = true;
+        attr_once.mark(attr_dev);
     }
     ProfScope ps("arc_stage_b", st);
     static const bool rows32 = getenv("PHONLP_ARC_ROWS32") != nullptr;  // A/B switch

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/phonlp_heads.h"
 
 namespace phonlp {
@@ -23,6 +25,22 @@ struct ProfScope {
 };
 
 constexpr int kWave = 64;
+
+// Launch-once work that is per DEVICE: hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the current device
+// only, so a process that drives several GPUs must repeat it on each.  Two threads racing here both do the (idempotent)
+// work; nobody skips it.
+struct PerDeviceOnce {
+    std::atomic<unsigned char> done[64];
+    bool pending(int *dev) {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        *dev = d;
+        return d < 0 || d >= 64 || !done[d].load(std::memory_order_acquire);
+    }
+    void mark(int d) {
+        if (d >= 0 && d < 64) done[d].store(1, std::memory_order_release);
+    }
+};
 
 #ifdef __HIPCC__
 // Workgroup barrier that orders LDS traffic only (s_waitcnt lgkmcnt(0) + s_barrier): unlike __syncthreads()

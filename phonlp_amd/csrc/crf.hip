@@ -153,12 +153,13 @@ extern "C" int phonlp_crf_viterbi(const float *logits, const float *trans, const
     size_t lds;
     if (plan_waves(L, T, true, wpb, wave_floats, lds))
         return fail(PHONLP_ERR_UNSUPPORTED, "crf_viterbi: L*T too large for the LDS trellis");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_once;
+    int attr_dev;
+    if (attr_once.pending(&attr_dev)) {
         if (hipFuncSetAttribute((const void *)viterbi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
             hipSuccess)
             return fail(PHONLP_ERR_LAUNCH, "crf_viterbi: cannot raise the dynamic LDS limit");
-        attr_set = true;
+        attr_once.mark(attr_dev);
     }
     ProfScope ps("viterbi", as_stream(stream));
     hipLaunchKernelGGL(viterbi_kernel, dim3(ceil_div(B, wpb)), dim3(wpb * 64), lds, as_stream(stream), logits, trans,
@@ -177,12 +178,13 @@ extern "C" int phonlp_crf_log_partition(const float *logits, const float *trans,
     size_t lds;
     if (plan_waves(L, T, false, wpb, wave_floats, lds))
         return fail(PHONLP_ERR_UNSUPPORTED, "crf_log_partition: L*T too large for LDS");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_once;
+    int attr_dev;
+    if (attr_once.pending(&attr_dev)) {
         if (hipFuncSetAttribute((const void *)crf_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024) != hipSuccess)
             return fail(PHONLP_ERR_LAUNCH, "crf_log_partition: cannot raise the dynamic LDS limit");
-        attr_set = true;
+        attr_once.mark(attr_dev);
     }
     ProfScope ps("crf_forward", as_stream(stream));
     hipLaunchKernelGGL(crf_forward_kernel, dim3(ceil_div(B, wpb)), dim3(wpb * 64), lds, as_stream(stream), logits,

@@ -166,14 +166,15 @@ extern "C" int phonlp_crf_nll_grad(const float *logits, const float *trans, cons
     if (ws_bytes < phonlp_crf_nll_grad_ws_bytes(B, T)) return fail(PHONLP_ERR_WORKSPACE, "crf_nll_grad: workspace too small");
     const size_t lds = ((size_t)2 * ((T * T + 3) & ~3) + (size_t)2 * L * T) * sizeof(float);
     if (lds > 150 * 1024) return fail(PHONLP_ERR_UNSUPPORTED, "crf_nll_grad: L*T too large for LDS");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_once;
+    int attr_dev;
+    if (attr_once.pending(&attr_dev)) {
         if (hipFuncSetAttribute((const void *)crf_nll_grad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024) != hipSuccess ||
             hipFuncSetAttribute((const void *)crf_nll_grad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024) != hipSuccess)
             return fail(PHONLP_ERR_LAUNCH, "crf_nll_grad: cannot raise the dynamic LDS limit");
-        attr_set = true;
+        attr_once.mark(attr_dev);
     }
     hipStream_t st = as_stream(stream);
     {

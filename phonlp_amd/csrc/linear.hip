@@ -812,13 +812,14 @@ int launch_linear(const char *tag, const float *X, long ldx, const float *W, lon
         static const bool small_tile = getenv("PHONLP_X6_TILE128") != nullptr;  // A/B switch: 128 x 128 split kernel
         const dim3 g1(a.num_m * a.num_n, nbatch);
         if (eng && !in_regs && !small_tile && M >= 1024 && K >= 8) {
-            static bool attr_set = false;
+            static PerDeviceOnce attr_once;
+    int attr_dev;
             constexpr int LDS = 2 * 3 * 384 * 32;
-            if (!attr_set) {
+            if (attr_once.pending(&attr_dev)) {
                 if (hipFuncSetAttribute((const void *)linear_split256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess ||
                     hipFuncSetAttribute((const void *)linear_split256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
                     return fail(PHONLP_ERR_LAUNCH, "linear: cannot raise the dynamic LDS limit");
-                attr_set = true;
+                attr_once.mark(attr_dev);
             }
             a.num_m = ceil_div(M, 256);
             const dim3 g2(a.num_m * a.num_n, nbatch);

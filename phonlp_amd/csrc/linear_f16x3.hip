@@ -649,14 +649,15 @@ int launch_linear_f16x3(const char *tag, const void *Xp, long pitch_x, const flo
     LinearArgs a{reinterpret_cast<const float *>(Xp), reinterpret_cast<const float *>(Wp), bias, pad_bias, Y, sentlens,
                  pitch_x, pitch_w, ldy, M, N, K16, L, relu, ceil_div(M, 256), ceil_div(N, 128), x_inv, w_inv};
     constexpr int LDS = 2 * 384 * 64, LDS_DMA = 3 * 384 * 64;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_once;
+    int attr_dev;
+    if (attr_once.pending(&attr_dev)) {
         if (hipFuncSetAttribute((const void *)linear_f16x3_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess ||
             hipFuncSetAttribute((const void *)linear_f16x3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess ||
             hipFuncSetAttribute((const void *)linear_f16x3_dma_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DMA) != hipSuccess ||
             hipFuncSetAttribute((const void *)linear_f16x3_dma_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DMA) != hipSuccess)
             return fail(PHONLP_ERR_LAUNCH, "linear_split: cannot raise the dynamic LDS limit");
-        attr_set = true;
+        attr_once.mark(attr_dev);
     }
     const bool stage_a = tag && !strcmp(tag, "linear:label_stage_a");
     static const bool reg_staged = getenv("PHONLP_X3_REG_STAGED") != nullptr;  // A/B switch: register-staged loop

@@ -503,14 +503,15 @@ extern "C" int phonlp_mst_one_root(const float *arc, const int32_t *sentlens, in
     const bool in_lds = mst_fits_lds(L);
     const int threads = L <= 256 ? 256 : (L + 63) / 64 * 64;
     size_t lds = mst_aux_bytes(L);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_once;
+    int attr_dev;
+    if (attr_once.pending(&attr_dev)) {
         if (hipFuncSetAttribute((const void *)mst_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
                 hipSuccess ||
             hipFuncSetAttribute((const void *)mst_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
                 hipSuccess)
             return fail(PHONLP_ERR_LAUNCH, "mst_one_root: cannot raise the dynamic LDS limit");
-        attr_set = true;
+        attr_once.mark(attr_dev);
     }
     ProfScope ps("mst", as_stream(stream));
     const size_t regions = mst_regions(B, L);

@@ -191,3 +191,32 @@ def test_patch_trainer_dev_loss_matches_reference(golden):
                  z["tag_lens"].tolist())
     got = trainer.dev_loss(dep_batch, pos_batch, ner_batch, 0.4, 0.2, 0.4)
     np.testing.assert_allclose(got, z["joint_losses"], rtol=1e-4)
+
+
+def test_patched_trainer_follows_weight_updates_and_eval_mode(golden):
+    """the packs are copies, so the seams must re-pack after a training step; and they must put the model
+    in eval mode like the reference (trainer.py:104,134,150), or the encoder's dropout stays on after update()."""
+    from phonlp_amd.compat import patch_trainer
+    from tests.stub_model import StubJointModel
+    z = golden("trainer_small.npz")
+    T = lambda k: torch.from_numpy(z[k])
+    dep_batch = (T("dep_tokens"), T("dep_first"), T("dep_mask"), T("dep_gold_head"), T("dep_gold_rel"),
+                 int(z["dep_nwords"]), z["dep_oidx"].tolist(), z["dep_lens"].tolist())
+    pos_batch = (T("tag_tokens"), T("tag_first"), T("gold_upos"), z["tag_oidx"].tolist(), z["tag_lens"].tolist())
+    model = StubJointModel(z)
+    trainer = patch_trainer(_StubTrainer(model), move_encoder=False)
+    before_dep, before_pos = trainer.predict_dep(dep_batch), trainer.predict_pos(pos_batch)
+    # (1) train mode: RoBERTa's dropout (p = 0.1) would make the encoder rows random; the seams switch it off
+    model.train()
+    assert trainer.predict_dep(dep_batch) == before_dep and not model.training
+    model.train()
+    assert trainer.predict_pos(pos_batch) == before_pos and not model.training
+    # (2) an in-place "optimizer step" on head weights after patching: predictions must be those of a fresh pack
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        for k in ("unlabeled.scorer.W_bilin.weight", "deprel.scorer.W_bilin.weight", "upos_clf.weight"):
+            model._heads[k].add_(torch.randn(model._heads[k].shape, generator=g) * 0.5)
+    after_dep, after_pos = trainer.predict_dep(dep_batch), trainer.predict_pos(pos_batch)
+    fresh = patch_trainer(_StubTrainer(model), move_encoder=False)
+    assert after_dep == fresh.predict_dep(dep_batch) and after_pos == fresh.predict_pos(pos_batch)
+    assert after_dep != before_dep and after_pos != before_pos
