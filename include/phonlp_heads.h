@@ -254,6 +254,19 @@ int phonlp_crf_nll_grad(const float *logits, const float *trans, const uint8_t *
                         const int32_t *gold_tags, int B, int L, int T, float scale, float *d_logits, float *d_trans,
                         void *ws, size_t ws_bytes, void *stream);
 
+/* The same gradient for callers that CANNOT ALLOCATE (code under HIP graph capture, tight training / serving loops,
+ * harnesses that forbid hipMalloc).  No counterpart in the reference.  The B x T x T scratch of phonlp_crf_nll_grad
+ * lives in a file-scope device array of phonlp_crf_nll_grad_static_max_bytes() = 4 MiB per GPU (held until the
+ * process ends); B*T*T*4 bytes beyond that is rejected with PHONLP_ERR_UNSUPPORTED.  The call allocates and frees
+ * nothing; the first call on a device looks the array's address up (hipGetSymbolAddress).  Every call on a GPU shares
+ * that GPU's array: calls that overlap on one GPU (two streams, two threads) race -- serialise them.  Nothing in the
+ * array needs clearing between calls (every entry read was written by the same call).  Same results as
+ * phonlp_crf_nll_grad, bit for bit. */
+size_t phonlp_crf_nll_grad_static_max_bytes(void);
+int phonlp_crf_nll_grad_static(const float *logits, const float *trans, const uint8_t *pad_mask,
+                               const int32_t *sentlens, const int32_t *gold_tags, int B, int L, int T, float scale,
+                               float *d_logits, float *d_trans, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Chu-Liu-Edmonds single-root MST -- models/common/chuliu_edmonds.py:133-169, applied to
  * arc[b, :len, :len] (rows = dependents, cols = heads, node 0 = ROOT), float64 arithmetic,

@@ -38,6 +38,8 @@ SIGNATURES = {
     "phonlp_crf_log_partition": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p]),
     "phonlp_crf_nll_grad_ws_bytes": (_z, [_i, _i]),
     "phonlp_crf_nll_grad": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, ctypes.c_float, _p, _p, _p, _z, _p]),
+    "phonlp_crf_nll_grad_static_max_bytes": (_z, []),
+    "phonlp_crf_nll_grad_static": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, ctypes.c_float, _p, _p, _p]),
     "phonlp_mst_ws_bytes": (_z, [_i, _i]),
     "phonlp_mst_one_root": (_i, [_p, _p, _i, _i, _p, _p, _p, _z, _p]),
     "phonlp_set_mst_fast_path": (_i, [_i]),

@@ -157,15 +157,14 @@ extern "C" size_t phonlp_crf_nll_grad_ws_bytes(int B, int T) {
     return (size_t)B * T * T * sizeof(float);
 }
 
-extern "C" int phonlp_crf_nll_grad(const float *logits, const float *trans, const uint8_t *pad_mask,
-                                   const int32_t *sentlens, const int32_t *gold_tags, int B, int L, int T, float scale,
-                                   float *d_logits, float *d_trans, void *ws, size_t ws_bytes, void *stream) {
-    if (!logits || !trans || !gold_tags || !d_logits || !d_trans || !ws || B <= 0 || L <= 0 || T <= 0)
-        return fail(PHONLP_ERR_SHAPE, "crf_nll_grad: bad argument");
-    if (T > 64) return fail(PHONLP_ERR_UNSUPPORTED, "crf_nll_grad: T > 64 (one lane per tag)");
-    if (ws_bytes < phonlp_crf_nll_grad_ws_bytes(B, T)) return fail(PHONLP_ERR_WORKSPACE, "crf_nll_grad: workspace too small");
+// both entry points: `part` = B x T x T floats of scratch (every entry is written by its sentence's workgroup before
+// the sum kernel reads it, so the scratch needs no clearing)
+static int crf_nll_grad_run(const char *who, const float *logits, const float *trans, const uint8_t *pad_mask,
+                            const int32_t *sentlens, const int32_t *gold_tags, int B, int L, int T, float scale,
+                            float *d_logits, float *d_trans, float *part, hipStream_t st) {
+    if (T > 64) return fail(PHONLP_ERR_UNSUPPORTED, "%s: T > 64 (one lane per tag)", who);
     const size_t lds = ((size_t)2 * ((T * T + 3) & ~3) + (size_t)2 * L * T) * sizeof(float);
-    if (lds > 150 * 1024) return fail(PHONLP_ERR_UNSUPPORTED, "crf_nll_grad: L*T too large for LDS");
+    if (lds > 150 * 1024) return fail(PHONLP_ERR_UNSUPPORTED, "%s: L*T too large for LDS", who);
     static PerDeviceOnce attr_once;
     int attr_dev;
     if (attr_once.pending(&attr_dev)) {
@@ -173,22 +172,63 @@ extern "C" int phonlp_crf_nll_grad(const float *logits, const float *trans, cons
                                 160 * 1024) != hipSuccess ||
             hipFuncSetAttribute((const void *)crf_nll_grad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024) != hipSuccess)
-            return fail(PHONLP_ERR_LAUNCH, "crf_nll_grad: cannot raise the dynamic LDS limit");
+            return fail(PHONLP_ERR_LAUNCH, "%s: cannot raise the dynamic LDS limit", who);
         attr_once.mark(attr_dev);
     }
-    hipStream_t st = as_stream(stream);
     {
         ProfScope ps("crf_nll_grad", st);
         if (T <= 16)
             hipLaunchKernelGGL(crf_nll_grad_kernel<true>, dim3(B), dim3(64), lds, st, logits, trans, pad_mask, sentlens,
-                               gold_tags, L, T, scale, d_logits, (float *)ws);
+                               gold_tags, L, T, scale, d_logits, part);
         else
             hipLaunchKernelGGL(crf_nll_grad_kernel<false>, dim3(B), dim3(64), lds, st, logits, trans, pad_mask, sentlens,
-                               gold_tags, L, T, scale, d_logits, (float *)ws);
+                               gold_tags, L, T, scale, d_logits, part);
         if (int rc = check_launch("crf_nll_grad_kernel")) return rc;
     }
     ProfScope ps("crf_dtrans_sum", st);
-    hipLaunchKernelGGL(crf_dtrans_sum_kernel, dim3(ceil_div(T * T, 4)), dim3(256), 0, st, (const float *)ws, B, T * T,
+    hipLaunchKernelGGL(crf_dtrans_sum_kernel, dim3(ceil_div(T * T, 4)), dim3(256), 0, st, (const float *)part, B, T * T,
                        scale, d_trans);
     return check_launch("crf_dtrans_sum_kernel");
+}
+
+extern "C" int phonlp_crf_nll_grad(const float *logits, const float *trans, const uint8_t *pad_mask,
+                                   const int32_t *sentlens, const int32_t *gold_tags, int B, int L, int T, float scale,
+                                   float *d_logits, float *d_trans, void *ws, size_t ws_bytes, void *stream) {
+    if (!logits || !trans || !gold_tags || !d_logits || !d_trans || !ws || B <= 0 || L <= 0 || T <= 0)
+        return fail(PHONLP_ERR_SHAPE, "crf_nll_grad: bad argument");
+    if (ws_bytes < phonlp_crf_nll_grad_ws_bytes(B, T)) return fail(PHONLP_ERR_WORKSPACE, "crf_nll_grad: workspace too small");
+    return crf_nll_grad_run("crf_nll_grad", logits, trans, pad_mask, sentlens, gold_tags, B, L, T, scale, d_logits,
+                            d_trans, (float *)ws, as_stream(stream));
+}
+
+// ---- the same with the scratch in a file-scope device array instead of a caller workspace: for callers that cannot
+// allocate (HIP graph capture, tight serving / training loops, harnesses that forbid hipMalloc).  The array's NAME is a
+// host-side stand-in, not a device address: its address on the current device comes from hipGetSymbolAddress, once per
+// device (each GPU holds its own copy at its own address), and only that pointer is ever handed to a kernel.
+constexpr size_t kStaticScratchFloats = (size_t)1 << 20;  // 4 MiB per GPU, held until the process ends
+static __device__ __align__(256) float scratch[kStaticScratchFloats];
+static std::atomic<float *> g_scratch_ptr[64];
+
+extern "C" size_t phonlp_crf_nll_grad_static_max_bytes(void) { return kStaticScratchFloats * sizeof(float); }
+
+extern "C" int phonlp_crf_nll_grad_static(const float *logits, const float *trans, const uint8_t *pad_mask,
+                                          const int32_t *sentlens, const int32_t *gold_tags, int B, int L, int T,
+                                          float scale, float *d_logits, float *d_trans, void *stream) {
+    if (!logits || !trans || !gold_tags || !d_logits || !d_trans || B <= 0 || L <= 0 || T <= 0)
+        return fail(PHONLP_ERR_SHAPE, "crf_nll_grad_static: bad argument");
+    if ((size_t)B * T * T > kStaticScratchFloats)
+        return fail(PHONLP_ERR_UNSUPPORTED, "crf_nll_grad_static: B*T*T = %zu floats exceeds the static scratch of %zu "
+                    "(use phonlp_crf_nll_grad with a workspace)", (size_t)B * T * T, kStaticScratchFloats);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
+        return fail(PHONLP_ERR_LAUNCH, "crf_nll_grad_static: no current device");
+    float *part = g_scratch_ptr[dev].load(std::memory_order_acquire);
+    if (!part) {  // first call on this device: its own copy of the array
+        const hipError_t e = hipGetSymbolAddress((void **)&part, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !part)
+            return fail(PHONLP_ERR_LAUNCH, "crf_nll_grad_static: hipGetSymbolAddress: %s", hipGetErrorString(e));
+        g_scratch_ptr[dev].store(part, std::memory_order_release);
+    }
+    return crf_nll_grad_run("crf_nll_grad_static", logits, trans, pad_mask, sentlens, gold_tags, B, L, T, scale,
+                            d_logits, d_trans, part, as_stream(stream));
 }
