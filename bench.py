@@ -36,45 +36,61 @@ PEAK_HBM_GBS = 8000.0
 
 
 def algorithmic_flops():
-    """SURVEY.md section 8(d) formulas, per sentence of parser length L (2*m*n*k)."""
+    """Per sentence of parser length L (2*m*n*k).  `total`: SURVEY.md section 8(d)'s formulas for the reference's path
+    (incl. the dense L x L x O label stage B and dep_hid as a layer of its own).  `executed`: what the timed step
+    actually multiplies -- dep_hid and the soft POS embedding are folded into the scorers' first layers (K = 768 + U),
+    the label scorer is evaluated at the decoded heads only (L x O dot products instead of L x L x O)."""
     D, H1 = E + TE, H + 1
     per_scorer = lambda o: 4 * L * D * H + 2 * L * H1 * H1 * o + 2 * L * L * H1 * o
     biaffine = 3 * per_scorer(1) + per_scorer(O)
     dep_hid = 2 * L * D * D
     pos = 2 * L * (E * H + H * U + U * TE) + 2 * (L - 1) * (E * H + H * U + U * TE)
     ner = 2 * (L - 1) * D * T
-    return {"total": biaffine + dep_hid + pos + ner, "label_stage_a": 2 * L * H1 * H1 * O}
+    Kf = E + U
+    executed = (4 * 4 * L * Kf * H                      # W1/W2 of the four scorers on [enc | tag probabilities]
+                + 3 * (2 * L * H1 * H1 + 2 * L * L * H1)  # arc scorers: stage A + stage B
+                + 2 * L * H1 * H1 * O + 2 * L * H1 * O    # label scorer: stage A + the contraction at the heads
+                + 2 * L * (E * H + H * U) + 2 * (L - 1) * (E * (H + T) + H * U + U * TE + TE * T))  # POS / tagger heads
+    return {"total": biaffine + dep_hid + pos + ner, "label_stage_a": 2 * L * H1 * H1 * O, "executed": executed}
 
 
-def cpu_baseline(sd, enc_dep, enc_tag, lens_dep, lens_tag, n_sample=48):
-    """The oracle on this host: GEMM heads through torch CPU (all intra-op threads), decoders per sentence in
-    numpy exactly as the reference drives them (single thread)."""
+def cpu_baseline(sd, enc_dep, enc_tag, lens_dep, lens_tag, n_sample=32):
+    """The oracle on this host (kind "port"): GEMM heads through torch CPU (all intra-op threads), decoders per sentence
+    in numpy exactly as the reference drives them (single thread).  One warm-up, then the minimum of three passes over a
+    bounded sample."""
     from oracle import heads_oracle as Or
     ed, et = enc_dep[:n_sample], enc_tag[:n_sample]
     ld, lt = lens_dep[:n_sample], lens_tag[:n_sample]
+    n_mst = min(n_sample, 12)
+    trans = sd["crit_ner._transitions"].numpy()
+    best = None
     with torch.no_grad():
         Or.dep_heads(ed[:4], ld[:4], sd, keep_label_scores=False)  # warm-up
-        t0 = time.perf_counter()
-        dep = Or.dep_heads(ed, ld, sd, keep_label_scores=False)
-        tag = Or.tagger_heads(et, lt, sd)
-        t_gemm = time.perf_counter() - t0
-    arc = dep["arc_logp"].numpy()
-    n_mst = min(n_sample, 24)
-    t0 = time.perf_counter()
-    for i in range(n_mst):
-        Or.chuliu_edmonds_one_root(arc[i][:ld[i], :ld[i]])
-    t_mst = (time.perf_counter() - t0) / n_mst
-    logits, trans = tag["ner_logits"].numpy(), sd["crit_ner._transitions"].numpy()
-    t0 = time.perf_counter()
-    for i in range(n_sample):
-        Or.viterbi_decode(logits[i, :lt[i]], trans)
-    t_vit = (time.perf_counter() - t0) / n_sample
-    per_sentence = t_gemm / n_sample + t_mst + t_vit
+        for _ in range(3):
+            t0 = time.perf_counter()
+            dep = Or.dep_heads(ed, ld, sd, keep_label_scores=False)
+            tag = Or.tagger_heads(et, lt, sd)
+            t_gemm = (time.perf_counter() - t0) / n_sample
+            arc, logits = dep["arc_logp"].numpy(), tag["ner_logits"].numpy()
+            t0 = time.perf_counter()
+            for i in range(n_mst):
+                Or.chuliu_edmonds_one_root(arc[i][:ld[i], :ld[i]])
+            t_mst = (time.perf_counter() - t0) / n_mst
+            t0 = time.perf_counter()
+            for i in range(n_sample):
+                Or.viterbi_decode(logits[i, :lt[i]], trans)
+            t_vit = (time.perf_counter() - t0) / n_sample
+            if best is None or t_gemm + t_mst + t_vit < sum(best):
+                best = (t_gemm, t_mst, t_vit)
+    t_gemm, t_mst, t_vit = best
     return {
-        "value": 1.0 / per_sentence, "unit": "sentences/s", "cores": torch.get_num_threads(), "kind": "port",
-        "sample": f"{n_sample} of {B} sentences (L={L}) for the torch-CPU heads and Viterbi, {n_mst} for the numpy MST; "
-                  f"per-sentence seconds: heads {t_gemm / n_sample:.4f}, mst {t_mst:.4f}, viterbi {t_vit:.4f}; "
-                  f"decoders single-threaded as in the reference",
+        "value": 1.0 / sum(best), "unit": "sentences/s", "cores": torch.get_num_threads(), "kind": "port",
+        "sample": f"min of 3 passes after a warm-up over {n_sample} of {B} sentences (L={L}) for the torch-CPU heads and "
+                  f"Viterbi, {n_mst} for the numpy MST; per-sentence seconds: heads {t_gemm:.4f}, mst {t_mst:.4f}, "
+                  f"viterbi {t_vit:.4f}; decoders single-threaded as in the reference",
+        "note": "a port, not the reference: its iterative MST needs ~9 ms per 128-word sentence where the reference's own "
+                "recursive chuliu_edmonds.py measured 75-120 ms (BASELINE.md section 2), so the reference itself is "
+                "several times slower than this baseline; the ratio says nothing about kernel quality, roofline.frac does",
     }
 
 
@@ -114,7 +130,7 @@ def main():
     from phonlp_amd import HeadWeights, TaskHeads
     from phonlp_amd import synthetic as S
     from phonlp_amd.profile import KernelTimer
-    from phonlp_amd import ops
+    from phonlp_amd import ops, _lib
 
     sd = S.make_state_dict(E, TE, H, U, O, T, seed=1234)
     heads = TaskHeads(HeadWeights.from_state_dict(sd, dev))
@@ -271,6 +287,7 @@ def main():
         kernels_ms = {k: round(v[1], 4) for k, v in sorted(kt_all.stats.items())}
 
     alone_ms = None
+    fused = heads.cfg["label_fused"]
     if rank == 0 and engine == 2:  # the dominant kernel with the chip to itself (same shapes and weights; untimed extra)
         w = heads.w
         KP = ops.kp(H)
@@ -278,12 +295,18 @@ def main():
         x1[:, H] = 1.0
         x1[:, H + 1:] = 0.0
         x1p, x1i = ops.split_rows(x1)
+        xf = torch.relu(torch.randn(B * L, 2 * KP, device=dev))
+        hd = torch.randint(0, L, (B, L), dtype=torch.int32, device=dev)
+        if fused:
+            run_a = lambda: ops.label_at_heads_fused(x1p, x1i, w.lab_Wbtc_s[0], w.lab_Wbtc_s[1], xf, hd, ld, H, O)
+        else:
+            run_a = lambda: ops.label_stage_a_split(x1p, x1i, w.lab_Wbt_s[0], w.lab_Wbt_s[1], B, L, H, O, w.lab_ones_col)
         for _ in range(2):
-            ops.label_stage_a_split(x1p, x1i, w.lab_Wbt_s[0], w.lab_Wbt_s[1], B, L, H, O, w.lab_ones_col)
+            run_a()
         torch.cuda.synchronize()
-        with KernelTimer(max_samples=16, only="linear:label_stage_a") as kt_alone:
+        with KernelTimer(max_samples=32, only="linear:label_stage_a") as kt_alone:
             for _ in range(8):
-                ops.label_stage_a_split(x1p, x1i, w.lab_Wbt_s[0], w.lab_Wbt_s[1], B, L, H, O, w.lab_ones_col)
+                run_a()
             torch.cuda.synchronize()
         alone_ms = kt_alone.stats["linear:label_stage_a"][1]
 
@@ -304,14 +327,39 @@ def main():
                        "element (split images), 3 v_mfma_f32_32x32x16_f16 products, f32 accumulate (fp32-grade error, "
                        "tests/test_gpu_parity.py::test_engines_against_fp64); small layers and stage B run bf16x6"}
         short = {0: "f32 MFMA", 1: "bf16x6", 2: "f16x3"}
-        kern = {0: "linear_kernel<128,128,2,2,1,0>", 1: "linear_split256_kernel<1>", 2: "linear_f16x3_dma_np_kernel<1>"}
+        kern = {0: "linear_kernel<128,128,2,2,1,0>", 1: "linear_split256_kernel<1>",
+                2: "linear_f16x3_dma_np_kernel<1>" + (" with the labels-at-heads epilogue (T never stored)" if fused else "")}
         peak_note = {0: "dense fp32 MFMA peak",
                      1: "algorithmic (fp32-equivalent) TFLOP/s; engine 1 peak = 2500 bf16 dense / 6 products",
                      2: "algorithmic (fp32-equivalent) TFLOP/s; engine 2 peak = 2500 f16 dense / 3 products"}
-        traffic = None
+        traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get(f"linear:label_stage_a@engine{engine}")
+            tj = json.load(open(tpath))
+            traffic = tj.get(f"linear:label_stage_a@engine{engine}" + ("+fused" if fused and engine == 2 else ""))
+            traffic_src = tj.get("source")
+        # the memory- / latency-bound stages the north star names, achieved HBM GB/s against the 8 TB/s peak: algorithmic
+        # bytes over the in-step launch duration of the untimed all-kernels pass
+        KP_ = ops.kp(H)
+        M_ = B * L
+        sec_bytes = {
+            "arc_stage_b": M_ * 6 * KP_ * 4 + M_ * 3 * KP_ * 4 + B * L * L * 4,  # X1/X2 of 3 scorers + their stage-A rows in, log-probs out
+            "viterbi": B * (L - 1) * T * 4 + T * T * 4 + B * (L - 1) * 4 + B * 4,
+            "mst": B * L * L * 4 * 2 + B * L * 4 + B * 4,                         # arc log-probs (read by both decode phases), heads + status out
+            "label_at_heads": M_ * O * KP_ * 4 + M_ * KP_ * 4 + M_ * 8,
+            "label_reduce": _lib.lib().phonlp_label_at_heads_fused_ws_bytes(B, L, H, O) + M_ * 8,  # per-tile shares in, ids out
+            "tagger_tail": M_ * (U + T + 2) * 4 + M_ * (H + T) * 4,
+            "split_rows": M_ * KP_ * 4 * 2,
+        }
+        secondary = []
+        for k, nbytes in sec_bytes.items():
+            if k in kernels_ms and kernels_ms[k] > 0:
+                gbs = nbytes / (kernels_ms[k] * 1e-3) / 1e9
+                secondary.append({"kernel": k, "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                  "frac": round(gbs / PEAK_HBM_GBS, 4), "ms_in_step": kernels_ms[k],
+                                  "algorithmic_bytes": nbytes})
+        sec_note = ("viterbi and mst are latency-bound (dependent chains of L steps / ~35 contraction rounds per decode on "
+                    "KBs of data): their HBM fraction is reported as the north star asks, the bound that holds is the chain")
         res = {
             "metric": "sentences/sec through POS+NER+dep heads at B=256,L=128",
             "value": sent / elapsed, "unit": "sentences/s", "n_gpus": world, "steps": args.steps,
@@ -323,10 +371,14 @@ def main():
             "config": {"workload": "BASELINE config 3: synthetic B=256 L=128 full heads incl. Chu-Liu-Edmonds MST "
                                    "(E=768, H=400, n_rel=33, n_ner=9, n_upos=24), encoder outputs resident in HBM",
                        "batch_per_gpu": B, "seq_len": L, "parallelism": f"sentence-sharded x{world}"},
-            "mfma_util_pct_whole_path": 100.0 * fl["total"] * B * args.steps / elapsed / (peak * 1e12),
+            "mfma_util_pct_whole_path_executed": 100.0 * fl["executed"] * B * args.steps / elapsed / (peak * 1e12),
+            "mfma_util_pct_whole_path_reference_flops": 100.0 * fl["total"] * B * args.steps / elapsed / (peak * 1e12),
+            "mfma_util_note": "executed = the FLOPs the timed step multiplies (folded dep_hid / POS embedding, labels at the "
+                              "decoded heads); reference_flops counts the reference's own algorithm incl. the dense label "
+                              "stage B (111 GFLOP/batch) and dep_hid (49 GFLOP/batch) that this path does not execute",
             "roofline": {"kernel": kern[engine] + " as bilinear stage A of the label scorer",
                          "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": traffic,
+                         "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
                          "peak_note": peak_note[engine],
                          "launches_timed": n, "mean_ms": mean_ms, "min_ms": min_ms,
                          "note": "timed inside the step, where the MST and tagger kernels share the chip with it "
@@ -337,6 +389,7 @@ def main():
                              "frac": fl["label_stage_a"] * B / (alone_ms * 1e-3) / 1e12 / peak,
                              "note": "the same kernel, shapes and weights with the chip to itself (X1 = relu(N(0,1))), "
                                      "8 launches after the timed region; `achieved` above is the in-step figure"}},
+            "roofline_secondary": secondary, "roofline_secondary_note": sec_note,
             "kernels_ms": kernels_ms,
             "kernels_ms_note": "mean per launch, every launch bracketed by HIP events" +
                                ("" if time_all else " in an extra untimed pass after the timed region (inside it only "

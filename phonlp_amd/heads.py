@@ -188,7 +188,7 @@ class TaskHeads:
             "mst_prio": int(env("PHONLP_MST_PRIO", "0")),        # HIP stream priority of the MST stream (-1 = high)
             "tag_prio": int(env("PHONLP_TAG_PRIO", "0")),        # ... of the tagger stream
             "tagger_fused": env("PHONLP_TAGGER_FUSED", "1") == "1",  # 0: pos_head + ner_emission instead of tagger_head
-            "tagger_late": int(env("PHONLP_TAGGER_LATE", "1")),  # tagger chain start: 0 batch start, 1 arc-done, 2 behind label W1/W2
+            "tagger_late": int(env("PHONLP_TAGGER_LATE", "2")),  # tagger chain start: 0 batch start, 1 arc-done, 2 behind label W1/W2 (default)
             "pos_fold": env("PHONLP_POS_FOLD", "1") == "1",      # scorers read [enc ; pos_dis] (K = 792) instead of [enc ; pos_emb]
             "rows4": env("PHONLP_ROWS4", "1") != "0",            # unfused form: T in the rows-by-4 layout
             "ones_col": env("PHONLP_ONES_COL", "1") == "1",      # unfused form: X1's ones column as a per-column bias
