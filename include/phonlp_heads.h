@@ -216,9 +216,11 @@ int phonlp_label_at_heads_rows4(const float *T4, const float *XF, const int32_t 
 
 /* The pair fused (engine 2): stage A's tiles are multiplied by the head's features and summed while they are still
  * in the accumulators, so T (1.8 GB at B=256, L=128) is neither written nor read; needs the heads first, i.e. runs
- * after the MST.  Wbtcp/wbtc_inv = split image of the [O*KPC, KP] matrix whose row o*KPC + d2 is row o*KP + d2 of the
- * phonlp_pack_bilinear image (KPC = phonlp_label_kpc(H) = KP rounded up to 32; the added rows zero).  Same scores as
- * phonlp_label_at_heads to fp32 rounding (another, fixed, summation order).  best_opt may be NULL. */
+ * after the MST.  The product is taken transposed (weight rows x words: an accumulator lane then holds one word and
+ * sixteen head features, and the contraction needs no cross-lane sums); the heads' features are gathered and transposed
+ * into the workspace first.  Wbtcp/wbtc_inv = split image of the [O*KPC, KP] matrix whose row o*KPC + d2 is row o*KP + d2
+ * of the phonlp_pack_bilinear image (KPC = phonlp_label_kpc(H) = KP rounded up to 32; the added rows zero).  Same scores
+ * as phonlp_label_at_heads to fp32 rounding (another, fixed, summation order).  best_opt may be NULL. */
 int phonlp_label_kpc(int H);
 size_t phonlp_label_at_heads_fused_ws_bytes(int B, int L, int H, int O);
 int phonlp_label_at_heads_fused(const void *X1p, const float *x1_inv, const void *Wbtcp, const float *wbtc_inv,

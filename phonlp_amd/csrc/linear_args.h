@@ -20,13 +20,12 @@ struct LinearArgs {
     // engine 2 only (linear_f16x3.hip): per-row / per-column powers of two that undo the operand scaling
     const float *row_scale, *col_scale;
     int rows4;  // linear_f16x3.hip: 1 = write Y in the "rows interleaved by 4" layout straight from the accumulators;
-                // 2 = labels-at-heads epilogue (no Y): partial scores P[col/32][row] = sum over the 32 columns of
-                //     C[row][col] * x2[hrow[row]][col % kpc]
-    const float *x2;       // mode 2: head-side features, row pitch ldx2 floats
-    const int32_t *hrow;   // mode 2: [M] row of x2 that holds the features of the word's head, -1 = none
-    float *P;              // mode 2: [N/32][M]
+                // 2 = labels-at-heads epilogue (no Y; rows = (relation, head feature) weight rows, columns = words):
+                //     P[row/32][col] = sum over the tile's 32 rows of C[row][col] * x2[(row % kpc) * ldx2 + col]
+    const float *x2;       // mode 2: head-side features of every word's head, transposed: [kpx][N], row pitch ldx2 floats
+    float *P;              // mode 2: [M/32][N]
     long ldx2;
-    int kpc, kpx;          // mode 2: columns per relation (multiple of 32) and how many of them are real
+    int kpc, kpx;          // mode 2: rows per relation (multiple of 32) and how many of them are real
     long bsx, bsw, bsy;  // batched launch (gridDim.y > 1): float strides of X, W, Y between the items
     int dbg;  // timing-only ablations (PHONLP_X3_ABLATION): 1 = epilogue without its global stores, 2 = no epilogue
 };

@@ -120,74 +120,87 @@ __device__ __forceinline__ void rows4_epilogue(f32x16 (&acc)[TM][TN], const Line
         }
 }
 
-// Labels-at-heads epilogue (mode 2): the tile of T = X1 . Wbt^T never leaves the chip.  Columns are (relation o,
-// head feature d2) with kpc (a multiple of 32) columns per relation, so each 32-column accumulator tile lies inside
-// one relation; every element is multiplied by the head's feature x2[hrow[row]][d2] and the 32 columns are summed
-// across the half-wave: P[col/32][row] is this tile's share of score[row][o].  A later pass adds the kpc/32 shares
-// of a relation in ascending order (label_reduce_kernel), so the sum has one fixed order: deterministic, and the
-// same whatever batch a sentence is decoded in.  8 values are summed per butterfly: three halving exchanges
-// (lanes trade value halves) and two plain ones; lane l of a half then holds the total of value (l >> 2) & 7.
+// Labels-at-heads epilogue (mode 2): the tile of T never leaves the chip.  The product is taken TRANSPOSED -- the
+// kernel's row operand is the bilinear weight image (rows = (relation o, head feature d2), kpc rows per relation, kpc a
+// multiple of 32 so a 32-row accumulator tile lies inside one relation) and its column operand the words' X1 image --
+// because of where the MFMA leaves the results: a lane holds ONE column (one word) and 16 rows (16 values of d2), so the
+// contraction over d2 with the head's features is a per-lane sum over its own registers, plus one exchange between
+// the two half-waves.  (With words as rows every sum ran across 32 lanes: eleven cross-lane exchanges per tile and
+// 0.40 of the kernel's 1.42 ms.)  The head's features come from x2t[d2][word] -- gathered through the decoded heads
+// and transposed once per batch (gather_heads_t_kernel) -- so a half-wave's load is 128 contiguous bytes.
+// P[row/32][word] = this tile's share of score[word][o]; label_reduce_kernel adds the kpc/32 shares of a relation in
+// ascending order, so the sum has one fixed order: deterministic, and the same whatever batch a sentence is decoded in.
 template <int TM, int TN>
 __device__ __forceinline__ void at_heads_epilogue(f32x16 (&acc)[TM][TN], const LinearArgs &a, int m0, int n0, int wm,
                                                   int wn, int lane) {
     const int half = lane >> 5, l32 = lane & 31;
-    const bool b4 = l32 & 16, b3 = l32 & 8, b2 = l32 & 4;
+    int word[TN];
+    float cs[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        word[j] = n0 + (wn * TN + j) * 32 + l32;
+        cs[j] = word[j] < a.N ? a.col_scale[word[j]] : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        const int base = m0 + (wm * TM + i) * 32 + 4 * half;
+        const int tile_row = m0 + (wm * TM + i) * 32;
+        const int d2b = tile_row % a.kpc + 4 * half;
+        float rs[16];
+        long xo[16];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {  // registers 8q .. 8q+7: rows base + (r&3) + 8*(r>>2)
-            long xoff[8];
-            float rs[8];
+        for (int r = 0; r < 16; ++r) {
+            const int o = (r & 3) + 8 * (r >> 2);
+            const int row = tile_row + 4 * half + o, d2 = d2b + o;
+            const bool valid = row < a.M && d2 < a.kpx;
+            rs[r] = valid ? a.row_scale[row] : 0.f;
+            xo[r] = (long)(valid ? d2 : 0) * a.ldx2;
+        }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int r = 8 * q + e;
-                const int row = base + (r & 3) + 8 * (r >> 2);
-                const int hr = row < a.M ? a.hrow[row] : -1;
-                xoff[e] = hr >= 0 ? (long)hr * a.ldx2 : -1;
-                rs[e] = row < a.M ? a.row_scale[row] : 0.f;
-            }
+        for (int j = 0; j < TN; ++j) {
+            const bool wok = word[j] < a.N;
+            const float *xc = a.x2 + (wok ? word[j] : 0);
+            float x[16];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int col = n0 + (wn * TN + j) * 32 + l32;
-                const int d2 = col % a.kpc;
-                const bool valid = col < a.N && d2 < a.kpx;
-                const float cs = valid ? a.col_scale[col] : 0.f;
-                float v[8];
+            for (int r = 0; r < 16; ++r) x[r] = xc[xo[r]];
+            float sum = 0.f;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float x = (valid && xoff[e] >= 0) ? a.x2[xoff[e] + d2] : 0.f;
-                    v[e] = acc[i][j][8 * q + e] * rs[e] * cs * x;
-                }
-                float k4[4], k2[2];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) k4[t] = (b4 ? v[4 + t] : v[t]) + __shfl_xor(b4 ? v[t] : v[4 + t], 16);
-#pragma unroll
-                for (int t = 0; t < 2; ++t) k2[t] = (b3 ? k4[2 + t] : k4[t]) + __shfl_xor(b3 ? k4[t] : k4[2 + t], 8);
-                float k = (b2 ? k2[1] : k2[0]) + __shfl_xor(b2 ? k2[0] : k2[1], 4);
-                k += __shfl_xor(k, 2);
-                k += __shfl_xor(k, 1);
-                // lane l32 holds value e = 4*b4 + 2*b3 + b2; one lane in four stores it
-                const int e = (l32 >> 2) & 7, r = 8 * q + e;
-                const int row = base + (r & 3) + 8 * (r >> 2);
-                const int g = (n0 + (wn * TN + j) * 32) >> 5;
-                if ((l32 & 3) == 0 && row < a.M && g * 32 < a.N) a.P[(long)g * a.M + row] = k;
-            }
+            for (int r = 0; r < 16; ++r) sum += acc[i][j][r] * rs[r] * x[r];
+            sum *= cs[j];
+            sum += __shfl_xor(sum, 32);  // the rows of the other half-wave
+            if (a.dbg == 1 && sum != 1234.5f) continue;
+            if (half == 0 && wok && tile_row < a.M) a.P[(long)(tile_row >> 5) * a.N + word[j]] = sum;
         }
     }
 }
 
-// hrow[m] = row of the head's features for word m = (b, i), 1 <= i < sentlens[b]; -1 elsewhere (ROOT, padding)
-__global__ void head_rows_kernel(const int32_t *heads, const int32_t *sentlens, int M, int L, int32_t *hrow) {
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= M) return;
-    const int b = m / L, i = m - b * L;
-    int v = -1;
-    if (i >= 1 && i < sentlens[b]) {
-        const int h = heads[m];
-        if (h >= 0 && h < L) v = b * L + h;
+// hrow[m] = row of the head's features for word m = (b, i), 1 <= i < sentlens[b]; -1 elsewhere (ROOT, padding); and
+// x2t[d2][m] = x2[hrow[m]][d2] (0 where there is no head): the head-side features gathered through the decoded heads,
+// transposed so that the epilogue above reads them word-contiguous.  Block = 32 words x 32 features through LDS.
+__global__ __launch_bounds__(1024) void gather_heads_t_kernel(const int32_t *heads, const int32_t *sentlens,
+                                                              const float *x2, long ldx2, int M, int L, int kpx,
+                                                              int32_t *hrow, float *x2t) {
+    __shared__ float tile[32][33];
+    __shared__ int hr[32];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int m0 = blockIdx.x * 32, d0 = blockIdx.y * 32;
+    if (ty == 0) {
+        const int m = m0 + tx;
+        int v = -1;
+        if (m < M) {
+            const int b = m / L, i = m - b * L;
+            if (i >= 1 && i < sentlens[b]) {
+                const int h = heads[m];
+                if (h >= 0 && h < L) v = b * L + h;
+            }
+            if (blockIdx.y == 0) hrow[m] = v;
+        }
+        hr[tx] = v;
     }
-    hrow[m] = v;
+    __syncthreads();
+    const int h = hr[ty];
+    tile[ty][tx] = (h >= 0 && d0 + tx < kpx) ? x2[(long)h * ldx2 + d0 + tx] : 0.f;
+    __syncthreads();
+    if (d0 + ty < kpx && m0 + tx < M) x2t[(long)(d0 + ty) * M + m0 + tx] = tile[tx][ty];
 }
 
 // rels[m] = argmax_o sum_{t < gpo} P[o*gpo + t][m] (shares added in ascending t; strict '>' in ascending o), 0 for
@@ -666,7 +679,7 @@ int launch_linear_f16x3(const char *tag, const void *Xp, long pitch_x, const flo
     a.rows4 = rows4;
     if (at_heads) {
         a.rows4 = 2;
-        a.x2 = at_heads->x2; a.hrow = at_heads->hrow; a.P = at_heads->P; a.ldx2 = at_heads->ldx2;
+        a.x2 = at_heads->x2; a.P = at_heads->P; a.ldx2 = at_heads->ldx2;
         a.kpc = at_heads->kpc; a.kpx = at_heads->kpx;
     }
     if (rows4 == 1 && (sentlens || relu || ((uintptr_t)Y & 15)))
@@ -761,7 +774,8 @@ extern "C" int phonlp_label_kpc(int H) { return (kp_of(H) + 31) / 32 * 32; }
 extern "C" size_t phonlp_label_at_heads_fused_ws_bytes(int B, int L, int H, int O) {
     if (B <= 0 || L <= 0 || H <= 0 || O <= 0) return 0;
     const size_t M = (size_t)B * L;
-    return align_up(M * sizeof(int32_t), 256) + align_up((size_t)O * (phonlp_label_kpc(H) / 32) * M * sizeof(float), 256);
+    return align_up(M * sizeof(int32_t), 256) + align_up((size_t)O * (phonlp_label_kpc(H) / 32) * M * sizeof(float), 256) +
+           align_up((size_t)kp_of(H) * M * sizeof(float), 256);
 }
 
 extern "C" int phonlp_label_at_heads_fused(const void *X1p, const float *x1_inv, const void *Wbtcp, const float *wbtc_inv,
@@ -776,13 +790,19 @@ extern "C" int phonlp_label_at_heads_fused(const void *X1p, const float *x1_inv,
     const int M = B * L, KP = kp_of(H), K16 = (KP + 15) / 16 * 16, KPC = phonlp_label_kpc(H);
     int32_t *hrow = (int32_t *)ws;
     float *P = (float *)((char *)ws + align_up((size_t)M * sizeof(int32_t), 256));
-    hipLaunchKernelGGL(head_rows_kernel, dim3(ceil_div(M, 256)), dim3(256), 0, st, heads, sentlens, M, L, hrow);
-    int rc = check_launch("head_rows_kernel");
-    if (rc) return rc;
+    float *x2t = (float *)((char *)P + align_up((size_t)O * (KPC / 32) * M * sizeof(float), 256));
+    {
+        ProfScope ps("gather_heads_t", st);
+        hipLaunchKernelGGL(gather_heads_t_kernel, dim3(ceil_div(M, 32), ceil_div(KP, 32)), dim3(1024), 0, st, heads, sentlens,
+                           XF + KP, 2L * KP, M, L, KP, hrow, x2t);
+        const int rc = check_launch("gather_heads_t_kernel");
+        if (rc) return rc;
+    }
+    // transposed product: rows = the weight image's (relation, head feature) rows, columns = words
     LinearArgs ah{};
-    ah.x2 = XF + KP; ah.ldx2 = 2L * KP; ah.hrow = hrow; ah.P = P; ah.kpc = KPC; ah.kpx = KP;
-    rc = launch_linear_f16x3("linear:label_stage_a", X1p, 4L * K16, x1_inv, Wbtcp, 4L * K16, wbtc_inv, nullptr, nullptr, 0, M,
-                             O * KPC, K16, 0, nullptr, 0, st, nullptr, 0, &ah);
+    ah.x2 = x2t; ah.ldx2 = M; ah.P = P; ah.kpc = KPC; ah.kpx = KP;
+    int rc = launch_linear_f16x3("linear:label_stage_a", Wbtcp, 4L * K16, wbtc_inv, X1p, 4L * K16, x1_inv, nullptr, nullptr,
+                                 0, O * KPC, M, K16, 0, nullptr, 0, st, nullptr, 0, &ah);
     if (rc) return rc;
     ProfScope ps("label_reduce", st);
     hipLaunchKernelGGL(label_reduce_kernel, dim3(ceil_div(M, 64)), dim3(512), 0, st, P, hrow, M, O, KPC / 32, rels, best_opt);
