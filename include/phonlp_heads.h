@@ -306,6 +306,15 @@ int phonlp_gather_labels(const int32_t *label_argmax, const int32_t *heads, cons
 int phonlp_gather_first_subword(const float *enc, const void *first_subword, int index_is_int64,
                                 const int32_t *sentlens, int B, int S, int L, int E, float *out, void *stream);
 
+/* Device-side unsort -- annotate_model.py:270,277,287 (util.unsort within the batch) and :291-293 (over the corpus),
+ * models/common/utils.py:189-195: the rows of a batch's result go straight to their sentences' places in a corpus-level
+ * table, dst[dest_row[b]][0..n) = src[b][col0..col0+n) with n = min(Ls - col0, Ld) (col0 = 1 drops the parser's ROOT
+ * column); dest_row[b] = the sentence's index in the input file (the two sort permutations composed on the host, which
+ * made them).  status_opt / fail_count_opt: *fail_count += number of non-zero entries of status [B] (MST failures),
+ * so a corpus needs one check at the end instead of one device->host round trip per batch. */
+int phonlp_scatter_rows(const int32_t *src, int B, int Ls, int col0, const int32_t *dest_row, int32_t *dst, int Ld,
+                        int n_dst, const int32_t *status_opt, int32_t *fail_count_opt, void *stream);
+
 /* Eval counts -- what the reference's scorers accumulate per corpus (models/pos/scorer.py:29-36 POS accuracy;
  * utils/conll18_ud_eval.py:531-532 UAS/LAS; tag-level NER agreement).  ADDS to counts[0..7] (int64, device):
  * sentences, words, pos_correct, ner_correct, uas_correct, las_correct, mst_failures, 0.  Tagger tensors are

@@ -210,28 +210,35 @@ def _annotate(self, text=None, input_file=None, output_file=None, batch_size=1, 
         print("The number of sentences: ", len(data))
     parser_batches = self.chunk_batches(self.process_data_parser(batch_text=data), batch_size)
     tagger_batches = self.chunk_batches(self.process_data_tagger(batch_text=data), batch_size)
-    pos_all, ner_all, dep_all = [], [], []
-    refresh_heads(self)
+    heads_ = refresh_heads(self)
+    dev = heads_.w.trans.device
+    # Corpus-level result tables on the device: every batch scatters its rows to the sentences' places in the input
+    # (the chunk sort and the batch sort composed on the host, ref :270,277,287,291-293), so the whole corpus comes
+    # back in ONE device->host copy and the MST status is checked once, not per batch.
+    n, wmax = len(data), max(len(s_) for s_ in data)
+    table = torch.zeros((4, n, wmax), dtype=torch.int32, device=dev)  # pos, ner, head, rel
+    mst_failures = torch.zeros(1, dtype=torch.int32, device=dev)
+    chunk_order = self.data_orig_idx
+    start = 0
     with torch.no_grad():
         for i in range(len(tagger_batches)):
             tok, fsw, _, _, oidx, lens = self.get_batch(i, tagger_batches)
             tok1, fsw1, _, _, oidx1, lens1 = self.get_batch(i, parser_batches)
-            out = self._amd_heads.annotate_batch(_encode(self, tok1, fsw1), lens1, _encode(self, tok, fsw), lens)
-            if int((out["mst_status"] != 0).sum().item()):
-                raise AssertionError("chuliu_edmonds_one_root: no finite single-root tree (reference asserts here)")
-            pos, ner = out["pos"].cpu().numpy(), out["ner"].cpu().numpy()
-            heads, rels = out["heads"].cpu().numpy(), out["rels"].cpu().numpy()
-            nb = len(lens)
-            dep_b = [[[str(int(heads[b][j])), r] for j, r in
-                      zip(range(1, lens1[b]), self.vocab["deprel"].unmap(rels[b][1:lens1[b]]))] for b in range(nb)]
-            pos_b = [[[u] for u in self.vocab["upos"].unmap(pos[b][:lens[b]])] for b in range(nb)]
-            ner_b = [self.vocab["ner_tag"].unmap(ner[b][:lens[b]]) for b in range(nb)]
-            dep_all += _unsort(dep_b, oidx1)
-            pos_all += _unsort(pos_b, oidx)
-            ner_all += _unsort(ner_b, oidx)
-    dep_all = _unsort(dep_all, self.data_orig_idx)
-    pos_all = _unsort(pos_all, self.data_orig_idx)
-    ner_all = _unsort(ner_all, self.data_orig_idx)
+            assert list(oidx) == list(oidx1), "tagger and parser batches must share their sort"
+            out = heads_.annotate_batch(_encode(self, tok1, fsw1), lens1, _encode(self, tok, fsw), lens)
+            dest = torch.tensor([chunk_order[start + k] for k in oidx], dtype=torch.int32).to(dev, non_blocking=True)
+            ops.scatter_rows(out["pos"], 0, dest, table[0])
+            ops.scatter_rows(out["ner"], 0, dest, table[1])
+            ops.scatter_rows(out["heads"], 1, dest, table[2], out["mst_status"], mst_failures)
+            ops.scatter_rows(out["rels"], 1, dest, table[3])
+            start += len(lens)
+    host = table.cpu().numpy()
+    if int(mst_failures.item()):
+        raise AssertionError("chuliu_edmonds_one_root: no finite single-root tree (reference asserts here)")
+    pos_all = [[[u] for u in self.vocab["upos"].unmap(host[0, k, :len(s_)])] for k, s_ in enumerate(data)]
+    ner_all = [self.vocab["ner_tag"].unmap(host[1, k, :len(s_)]) for k, s_ in enumerate(data)]
+    dep_all = [[[str(int(h)), r] for h, r in zip(host[2, k, :len(s_)], self.vocab["deprel"].unmap(host[3, k, :len(s_)]))]
+               for k, s_ in enumerate(data)]
     if text is not None:
         return (data, pos_all, ner_all, dep_all)
     with open(output_file, "w") as f:

@@ -124,9 +124,39 @@ __global__ __launch_bounds__(64) void ner_entity_counts_kernel(const int32_t *pr
     if (n_gold) atomicAdd(&counts[2], n_gold);
 }
 
+// Device-side unsort (ref annotate_model.py:270,277,287,291-293 / models/common/utils.py:189-195): the batch's rows go
+// straight to their place in a corpus-level table: dst[dest_row[b]][0 .. n) = src[b][col0 .. col0 + n), n = min(Ls - col0,
+// Ld); the rest of the destination row is left as it is.  fail_count (optional) += number of non-zero status entries.
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const int32_t *src, int B, int Ls, int col0,
+                                                           const int32_t *dest_row, int32_t *dst, int Ld, int n_dst,
+                                                           const int32_t *status, int32_t *fail_count) {
+    const int n = (Ls - col0) < Ld ? (Ls - col0) : Ld;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < (long)B * n; idx += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(idx / n), c = (int)(idx % n);
+        const int r = dest_row[b];
+        if (r >= 0 && r < n_dst) dst[(long)r * Ld + c] = src[(long)b * Ls + col0 + c];
+    }
+    if (status && fail_count && blockIdx.x == 0 && threadIdx.x == 0) {
+        int f = 0;
+        for (int b = 0; b < B; ++b) f += status[b] != 0;
+        if (f) atomicAdd(fail_count, f);
+    }
+}
+
 }  // namespace phonlp
 
 using namespace phonlp;
+
+extern "C" int phonlp_scatter_rows(const int32_t *src, int B, int Ls, int col0, const int32_t *dest_row, int32_t *dst,
+                                   int Ld, int n_dst, const int32_t *status_opt, int32_t *fail_count_opt, void *stream) {
+    if (!src || !dest_row || !dst || B <= 0 || Ls <= 0 || Ld <= 0 || col0 < 0 || col0 >= Ls || n_dst <= 0)
+        return fail(PHONLP_ERR_SHAPE, "scatter_rows: bad argument");
+    ProfScope ps("scatter_rows", as_stream(stream));
+    const long work = (long)B * Ls;
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)((work + 255) / 256 < 512 ? (work + 255) / 256 : 512)), dim3(256),
+                       0, as_stream(stream), src, B, Ls, col0, dest_row, dst, Ld, n_dst, status_opt, fail_count_opt);
+    return check_launch("scatter_rows_kernel");
+}
 
 extern "C" int phonlp_gather_first_subword(const float *enc, const void *first_subword, int index_is_int64,
                                            const int32_t *sentlens, int B, int S, int L, int E, float *out,

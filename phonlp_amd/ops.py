@@ -574,6 +574,17 @@ def label_at_heads_fused(x1p: Tensor, x1_inv: Tensor, wbtcp: Tensor, wbtc_inv: T
     return rels, best
 
 
+def scatter_rows(src: Tensor, col0: int, dest_row: Tensor, dst: Tensor, status: Optional[Tensor] = None,
+                 fail_count: Optional[Tensor] = None) -> None:
+    """dst[dest_row[b], :n] = src[b, col0:col0+n] (device-side unsort, include/phonlp_heads.h); in place on dst."""
+    _need(src, torch.int32, "src")
+    _need(dest_row, torch.int32, "dest_row")
+    _need(dst, torch.int32, "dst")
+    B, Ls = src.shape
+    check(lib().phonlp_scatter_rows(_p(src), B, Ls, int(col0), _p(dest_row), _p(dst), dst.shape[1], dst.shape[0],
+                                    _p(status), _p(fail_count), _stream()), "phonlp_scatter_rows")
+
+
 @torch.library.custom_op("phonlp_amd::eval_counts_into", mutates_args=("counts",))
 def eval_counts_into(counts: Tensor, pos: Tensor, ner: Tensor, heads: Tensor, rels: Tensor, gold_pos: Tensor,
                      gold_ner: Tensor, gold_head: Tensor, gold_rel: Tensor, lens_tag: Tensor, lens_dep: Tensor,
