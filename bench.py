@@ -328,7 +328,7 @@ def main():
                        "tests/test_gpu_parity.py::test_engines_against_fp64); small layers and stage B run bf16x6"}
         short = {0: "f32 MFMA", 1: "bf16x6", 2: "f16x3"}
         kern = {0: "linear_kernel<128,128,2,2,1,0>", 1: "linear_split256_kernel<1>",
-                2: "linear_f16x3_dma_np_kernel<1>" + (" with the labels-at-heads epilogue (T never stored)" if fused else "")}
+                2: "linear_f16x3_dma_kernel<1, false>" + (" with the labels-at-heads epilogue (T never stored)" if fused else "")}
         peak_note = {0: "dense fp32 MFMA peak",
                      1: "algorithmic (fp32-equivalent) TFLOP/s; engine 1 peak = 2500 bf16 dense / 6 products",
                      2: "algorithmic (fp32-equivalent) TFLOP/s; engine 2 peak = 2500 f16 dense / 3 products"}

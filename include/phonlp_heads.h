@@ -15,6 +15,10 @@
  *    work, they never synchronise, allocate or free;
  *  - scratch memory is caller-provided: ask `phonlp_*_ws_bytes()` first, pass `ws`/`ws_bytes`;
  *  - return value: PHONLP_OK or a negative PHONLP_ERR_*; `phonlp_last_error()` gives text;
+ *  - threads: every entry point may be called from several host threads at once provided the calls do not share
+ *    output / workspace memory (error text is thread-local; the per-device launch-once setup is race-tolerant).  The
+ *    process-wide SWITCHES are not synchronised -- phonlp_set_gemm_engine, phonlp_set_mst_fast_path and the profiling
+ *    calls (phonlp_profile_*): set them before starting worker threads, not while calls are in flight;
  *  - `sentlens[b]` = number of real rows (words, incl. ROOT on the parser path) of sentence b;
  *    rows/tokens at index >= sentlens[b] are padding.
  */

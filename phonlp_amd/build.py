@@ -39,6 +39,17 @@ def stale():
     return any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps)
 
 
+def build_ablation(verbose=True):
+    """Timing-only variant (tools/fused_probe.py, tools/x3_abl.sh): the GEMM kernels with their ablation branches
+    (-DPHONLP_ABLATION; PHONLP_X3_ABLATION / PHONLP_X6_ABLATION select them at run time).  The shipped library has none."""
+    out = os.path.join(HERE, "..", "tools", "libphonlp_heads_ablation.so")
+    cmd = [HIPCC] + FLAGS + ["-DPHONLP_ABLATION", "-shared", "-o", out] + sources()
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return out
+
+
 def build_stamps(verbose=True):
     """Diagnostic variant (tools/mst_stamps.py): the MST kernels with per-phase cycle counters (-DMST_STAMPS)."""
     out = os.path.join(HERE, "..", "tools", "libphonlp_heads_stamps.so")
@@ -76,5 +87,7 @@ def build(force=False, verbose=True):
 if __name__ == "__main__":
     if "--stamps" in sys.argv:
         build_stamps()
+    elif "--ablation" in sys.argv:
+        build_ablation()
     else:
         build(force="--force" in sys.argv)

@@ -823,7 +823,13 @@ int launch_linear(const char *tag, const float *X, long ldx, const float *W, lon
             }
             a.num_m = ceil_div(M, 256);
             const dim3 g2(a.num_m * a.num_n, nbatch);
+#ifdef PHONLP_ABLATION
             static const int abl = getenv("PHONLP_X6_ABLATION") ? atoi(getenv("PHONLP_X6_ABLATION")) : 0;  // timing only
+#else
+            constexpr int abl = 0;  // the ablated loop variants are only instantiated in -DPHONLP_ABLATION builds
+#endif
+            (void)abl;
+#ifdef PHONLP_ABLATION
             if (abl) {
                 const void *fns[] = {(const void *)linear_split256_kernel<0, 1>, (const void *)linear_split256_kernel<0, 2>,
                                      (const void *)linear_split256_kernel<0, 3>};
@@ -831,7 +837,9 @@ int launch_linear(const char *tag, const float *X, long ldx, const float *W, lon
                 if (abl == 1) hipLaunchKernelGGL((linear_split256_kernel<0, 1>), g2, dim3(256), LDS, stream, a);
                 else if (abl == 2) hipLaunchKernelGGL((linear_split256_kernel<0, 2>), g2, dim3(256), LDS, stream, a);
                 else hipLaunchKernelGGL((linear_split256_kernel<0, 3>), g2, dim3(256), LDS, stream, a);
-            } else if (stage_a) hipLaunchKernelGGL((linear_split256_kernel<1>), g2, dim3(256), LDS, stream, a);
+            } else
+#endif
+            if (stage_a) hipLaunchKernelGGL((linear_split256_kernel<1>), g2, dim3(256), LDS, stream, a);
             else hipLaunchKernelGGL((linear_split256_kernel<0>), g2, dim3(256), LDS, stream, a);
             return check_launch("linear_split256_kernel");
         }

@@ -114,7 +114,9 @@ __device__ __forceinline__ void rows4_epilogue(f32x16 (&acc)[TM][TN], const Line
                 v.y = acc[i][j][4 * g + 1] * rs.y * cs[j] + cb[j];
                 v.z = acc[i][j][4 * g + 2] * rs.z * cs[j] + cb[j];
                 v.w = acc[i][j][4 * g + 3] * rs.w * cs[j] + cb[j];
+#ifdef PHONLP_ABLATION
                 if (a.dbg == 1 && v.x != 1234.5f) continue;
+#endif
                 *reinterpret_cast<float4 *>(a.Y + ((long)(row >> 2) * a.N + col[j]) * 4) = v;
             }
         }
@@ -167,7 +169,9 @@ __device__ __forceinline__ void at_heads_epilogue(f32x16 (&acc)[TM][TN], const L
             for (int r = 0; r < 16; ++r) sum += acc[i][j][r] * rs[r] * x[r];
             sum *= cs[j];
             sum += __shfl_xor(sum, 32);  // the rows of the other half-wave
+#ifdef PHONLP_ABLATION
             if (a.dbg == 1 && sum != 1234.5f) continue;
+#endif
             if (half == 0 && wok && tile_row < a.M) a.P[(long)(tile_row >> 5) * a.N + word[j]] = sum;
         }
     }
@@ -231,142 +235,30 @@ __global__ __launch_bounds__(512) void label_reduce_kernel(const float *P, const
     }
 }
 
-// 256 x 128 block tile, four waves of 128 x 64 (8 accumulator tiles), k16 stages, two 24 KB LDS buffers, one
-// barrier per stage; two blocks per CU cover each other's barriers.  a.X / a.W are the split images (row pitch
-// a.ldx / a.ldw BYTES), a.K = K16.  Per stage and wave: 12 ds_read_b128 feed 24 MFMAs; per thread 6 global
-// loads + 6 ds_write_b128 and no other VALU work.
+// 256 x 128 block tile, four waves of 128 x 64 (8 accumulator tiles), k16 stages.  a.X / a.W are the split images (row
+// pitch a.ldx / a.ldw BYTES), a.K = K16.  Per stage and wave: 12 ds_read_b128 feed 24 MFMAs and there is no other VALU
+// work.
 //
 // LDS image of a stage: row R at R*64 bytes (rows 0-255 A tile, 256-383 B tile), chunk c stored at slot
-// c ^ ((R>>2)&3): the 16 rows of a ds_read_b128 lane group cover all 64 banks, and so do the 4 rows x 4 chunks of
-// a ds_write_b128 lane group.  Rows past M / N are not zero-filled: their pointers are clamped to the last valid
-// row and the garbage only reaches outputs the epilogue never stores.
-template <int TAG>
-__global__ __launch_bounds__(256, 2) void linear_f16x3_kernel(LinearArgs a) {
-    constexpr int BM = 256, BN = 128, WM = 2, WN = 2, TM = 4, TN = 2;
-    constexpr int ROWS = BM + BN, BUF = ROWS * 64;
-    static_assert(WM * WN * 32 * (TN * 32 + 4) * 4 <= 2 * BUF, "epilogue patch must fit");
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int ntiles = a.num_m * a.num_n;
-    const int nst = a.K >> 4;
-    int m0, n0;
-    {   // one tile per block; blocks b, b+8, ... (one XCD) take a contiguous chunk of a 4-tall column-major walk
-        const int xg = blockIdx.x & 7, jl = blockIdx.x >> 3;
-        const int q = ntiles >> 3, r = ntiles & 7;
-        const int t = (xg < r ? xg * (q + 1) : r * (q + 1) + (xg - r) * q) + jl;
-        constexpr int GM = 4;
-        const int per_group = GM * a.num_n;
-        const int g = t / per_group;
-        const int first_m = g * GM;
-        const int gsz = (a.num_m - first_m) < GM ? (a.num_m - first_m) : GM;
-        const int in = t - g * per_group;
-        m0 = (first_m + in % gsz) * BM;
-        n0 = (in / gsz) * BN;
-    }
-    // staging map: thread -> chunk c = tid&3 of rows (tid>>2) + 64q; q 0-3 are A rows, 4-5 B rows
-    const int r0 = tid >> 2, c = tid & 3;
-    const unsigned char *src[6];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        int row = m0 + r0 + 64 * q;
-        row = row < a.M ? row : a.M - 1;
-        src[q] = reinterpret_cast<const unsigned char *>(a.X) + (long)row * a.ldx + c * 16;
-    }
-#pragma unroll
-    for (int q = 4; q < 6; ++q) {
-        int row = n0 + r0 + 64 * (q - 4);
-        row = row < a.N ? row : a.N - 1;
-        src[q] = reinterpret_cast<const unsigned char *>(a.W) + (long)row * a.ldw + c * 16;
-    }
-    const int wofs = r0 * 64 + ((c ^ ((r0 >> 2) & 3)) << 4);
-    u32x4 R[6];
-    auto load_stage = [&](int st) {
-#pragma unroll
-        for (int q = 0; q < 6; ++q) R[q] = *reinterpret_cast<const u32x4 *>(src[q] + (long)st * 64);
-    };
-    auto store_stage = [&](unsigned char *buf) {
-#pragma unroll
-        for (int q = 0; q < 6; ++q) *reinterpret_cast<u32x4 *>(buf + wofs + q * 64 * 64) = R[q];
-    };
-
-    const int r = lane & 31, hh = lane >> 5;
-    const int sw = (r >> 2) & 3;
-    const int off_h = ((2 * hh) ^ sw) << 4, off_l = ((2 * hh + 1) ^ sw) << 4;
-    const int a_ofs = (wm * 128 + r) * 64;
-    const int b_ofs = (BM + wn * 64 + r) * 64;
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    struct Frags {
-        u32x4 ah[TM], al[TM], bh[TN], bl[TN];
-    };
-    auto read_frags = [&](const unsigned char *buf, Frags &f) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            f.bh[j] = *reinterpret_cast<const u32x4 *>(buf + b_ofs + j * 2048 + off_h);
-            f.bl[j] = *reinterpret_cast<const u32x4 *>(buf + b_ofs + j * 2048 + off_l);
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            f.al[i] = *reinterpret_cast<const u32x4 *>(buf + a_ofs + i * 2048 + off_l);
-            f.ah[i] = *reinterpret_cast<const u32x4 *>(buf + a_ofs + i * 2048 + off_h);
-        }
-    };
-    auto mma_frags = [&](const Frags &f) {
-#define PHONLP_X3_ROUND(AA, BB)                      \
-    _Pragma("unroll") for (int i = 0; i < TM; ++i)   \
-    _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] = PHONLP_F16_MFMA(f.AA[i], f.BB[j], acc[i][j]);
-        PHONLP_X3_ROUND(al, bh)
-        PHONLP_X3_ROUND(ah, bl)
-        PHONLP_X3_ROUND(ah, bh)
-#undef PHONLP_X3_ROUND
-    };
-
-    // prologue: stage 0 in buffer 0, stage 1 in registers
-    load_stage(0);
-    store_stage(lds);
-    if (nst > 1) load_stage(1);
-    lds_barrier();
-    for (int s = 0; s < nst; ++s) {
-        unsigned char *cur = lds + (s & 1) * BUF, *nxt = lds + ((s + 1) & 1) * BUF;
-        Frags f;
-        read_frags(cur, f);
-        if (s + 1 < nst) store_stage(nxt);
-        if (s + 2 < nst) load_stage(s + 2);
-        mma_frags(f);
-        lds_barrier();
-    }
-    if (a.rows4 == 2) {
-        at_heads_epilogue<TM, TN>(acc, a, m0, n0, wm, wn, lane);
-        return;
-    }
-    if (a.rows4) {
-        rows4_epilogue<TM, TN>(acc, a, m0, n0, wm, wn, lane);
-        return;
-    }
-    linear_epilogue<TM, TN, WM, WN>(acc, reinterpret_cast<float *>(lds), a, m0, n0, wm, wn, lane, wave);
-}
-
-// The same tile with the operands streamed global -> LDS by the LDS-DMA path (global_load_lds_dwordx4: 16 bytes per
-// lane land at M0 + lane*16, no VGPR staging) into a ring of THREE stage buffers, so the loads of stage s+2 are in
-// flight while stage s is multiplied: two whole stages (~1500-3000 cycles) cover the L2 / Infinity-Cache latency that
-// the register-staged loop above (one stage of lookahead) leaves exposed.  A wave-load covers 16 rows x 64 bytes; lane
-// i writes slot i&3 of row i>>2, so it FETCHES chunk (i&3) ^ ((i>>4)&3) of that row: the swizzle of the LDS image is
-// applied on the global side.  The DMA and its s_waitcnt are inline asm: hipcc's own waitcnt insertion would make
-// every LDS read wait for all LDS-DMA loads in flight (it cannot tell the ring buffers apart).
+// c ^ ((R>>2)&3): the 16 rows of a ds_read_b128 lane group cover all 64 banks.  Rows past M / N are not zero-filled:
+// their pointers are clamped to the last valid row and the garbage only reaches outputs the epilogue never stores.
+//
+// The operands are streamed global -> LDS by the LDS-DMA path (global_load_lds_dwordx4: 16 bytes per lane land at
+// M0 + lane*16, no VGPR staging) into a ring of THREE stage buffers, so the loads of stage s+2 are in flight while stage
+// s is multiplied: two whole stages (~1500-3000 cycles) cover the L2 / Infinity-Cache latency.  A wave-load covers 16
+// rows x 64 bytes; lane i writes slot i&3 of row i>>2, so it FETCHES chunk (i&3) ^ ((i>>4)&3) of that row: the swizzle
+// of the LDS image is applied on the global side.  The DMA and its s_waitcnt are inline asm: hipcc's own waitcnt
+// insertion would make every LDS read wait for all LDS-DMA loads in flight (it cannot tell the ring buffers apart).
+//
+// PREFETCH chooses the loop form (launch_linear_f16x3 picks by K): true = fragments double-buffered in registers, the
+// ds_read_b128 of stage s+1 issued BEFORE the MFMAs of stage s (256 VGPRs; wins for K >= 512: 0.456 vs 0.482 ms on the
+// W1/W2 layer); false = fragments read at the top of their own stage (196 VGPRs; wins for short K, i.e. label stage A,
+// where the leaner epilogue matters more: 1.55 vs 1.65 ms).
 __device__ __forceinline__ void lds_dma16(const unsigned char *gptr, unsigned lds_addr) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_addr), "v"(gptr) : "memory", "m0");
 }
 
-template <int TAG>
+template <int TAG, bool PREFETCH>
 __global__ __launch_bounds__(256, 2) void linear_f16x3_dma_kernel(LinearArgs a) {
     constexpr int BM = 256, BN = 128, WM = 2, WN = 2, TM = 4, TN = 2, NBUF = 3;
     constexpr int ROWS = BM + BN, BUF = ROWS * 64;
@@ -378,11 +270,11 @@ __global__ __launch_bounds__(256, 2) void linear_f16x3_dma_kernel(LinearArgs a) 
     const int ntiles = a.num_m * a.num_n;
     const int nst = a.K >> 4;
     int m0, n0;
-    {
+    {   // one tile per block; blocks b, b+8, ... (one XCD) take a contiguous chunk of a GM-tall column-major walk
         const int xg = blockIdx.x & 7, jl = blockIdx.x >> 3;
         const int q = ntiles >> 3, r = ntiles & 7;
         const int t = (xg < r ? xg * (q + 1) : r * (q + 1) + (xg - r) * q) + jl;
-        constexpr int GM = 4;
+        const int GM = a.gm > 0 ? a.gm : 4;
         const int per_group = GM * a.num_n;
         const int g = t / per_group;
         const int first_m = g * GM;
@@ -426,8 +318,6 @@ __global__ __launch_bounds__(256, 2) void linear_f16x3_dma_kernel(LinearArgs a) 
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    // Fragments are double-buffered in registers: the ds_read_b128 of stage s+1 are issued BEFORE the MFMAs of stage
-    // s, so the matrix pipe never waits for an LDS read of its own stage.
     struct Frags {
         u32x4 ah[TM], al[TM], bh[TN], bl[TN];
     };
@@ -444,7 +334,7 @@ __global__ __launch_bounds__(256, 2) void linear_f16x3_dma_kernel(LinearArgs a) 
             f.ah[i] = *reinterpret_cast<const u32x4 *>(buf + a_ofs + i * 2048 + off_h);
         }
     };
-    auto mma_frags = [&](const Frags &f) {
+    auto mma_frags = [&](const Frags &f) {  // smallest terms first
 #define PHONLP_X3_ROUND(AA, BB)                      \
     _Pragma("unroll") for (int i = 0; i < TM; ++i)   \
     _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] = PHONLP_F16_MFMA(f.AA[i], f.BB[j], acc[i][j]);
@@ -453,57 +343,76 @@ __global__ __launch_bounds__(256, 2) void linear_f16x3_dma_kernel(LinearArgs a) 
         PHONLP_X3_ROUND(ah, bh)
 #undef PHONLP_X3_ROUND
     };
-    // one stage: fetch stage s+2 into the buffer whose readers are all past the previous barrier, publish stage s+1
-    // (own pieces landed, then the barrier), prefetch its fragments, multiply stage s.
-    auto stage = [&](int s, const Frags &fc, Frags &fn) {
-        if (s + 2 < nst) issue_stage(s + 2, (s + 2) % NBUF);
-        if (s + 1 < nst) {
+
+    issue_stage(0, 0);
+    if (nst > 1) {
+        issue_stage(1, 1);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if constexpr (PREFETCH) {
+        // one stage: fetch stage s+2 into the buffer whose readers are all past the previous barrier, publish stage s+1
+        // (own pieces landed, then the barrier), prefetch its fragments, multiply stage s.
+        auto stage = [&](int s, const Frags &fc, Frags &fn) {
+            if (s + 2 < nst) issue_stage(s + 2, (s + 2) % NBUF);
+            if (s + 1 < nst) {
+                if (s + 2 < nst) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                lds_barrier();
+                read_frags((s + 1) % NBUF, fn);
+            }
+            mma_frags(fc);
+        };
+        Frags f0, f1;
+        read_frags(0, f0);
+        // stage s+2 goes to buffer (s+2)%3, last read as stage s-1 by the prefetch of iteration s-2: every wave has been
+        // through the barrier of iteration s-1 since (lds_barrier waits for the wave's outstanding LDS reads first).
+        // The steady state is branch-free (a conditional around the prefetch makes hipcc wait for ALL LDS reads at the
+        // join, i.e. in front of the MFMAs); the last stages run through the guarded form.
+        auto stage_full = [&](int s, const Frags &fc, Frags &fn) {
+            issue_stage(s + 2, (s + 2) % NBUF);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            lds_barrier();
+            read_frags((s + 1) % NBUF, fn);
+            // MFMAs are register-only: unpinned, hipcc hoists them above the barrier, and the next stage's MFMAs then
+            // sit right behind their own reads.  An empty asm that "modifies" every accumulator pins them behind the
+            // reads (sched_barrier does too, but drives the register allocator into 500 spills here).
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(acc[i][j]));
+            mma_frags(fc);
+        };
+        int s = 0;
+        for (; s + 3 < nst; s += 2) {
+            stage_full(s, f0, f1);
+            stage_full(s + 1, f1, f0);
+        }
+        for (; s < nst; s += 2) {
+            stage(s, f0, f1);
+            if (s + 1 < nst) stage(s + 1, f1, f0);
+        }
+        lds_barrier();  // the epilogue's LDS patch aliases the stage buffers
+    } else {
+        int cur = 0;
+        for (int s = 0; s < nst; ++s) {
+            const int nxt2 = cur == 0 ? 2 : cur - 1;  // (cur + 2) % 3: last read in iteration s-1, behind that barrier
+            if (s + 2 < nst) issue_stage(s + 2, nxt2);
+            Frags f;
+            read_frags(cur, f);
+            mma_frags(f);
+            // stage s+1 (issued one iteration ago) must have landed before anyone reads it; the 6 loads of stage s+2
+            // issued above may stay in flight
             if (s + 2 < nst) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             lds_barrier();
-            read_frags((s + 1) % NBUF, fn);
+            cur = cur == 2 ? 0 : cur + 1;
         }
-        mma_frags(fc);
-    };
-    issue_stage(0, 0);
-    if (nst > 1) {
-        issue_stage(1, 1);
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    __builtin_amdgcn_s_barrier();
-    Frags f0, f1;
-    read_frags(0, f0);
-    // stage s+2 goes to buffer (s+2)%3, last read as stage s-1 by the prefetch of iteration s-2: every wave has been
-    // through the barrier of iteration s-1 since (lds_barrier waits for the wave's outstanding LDS reads first)
-    // The steady state is branch-free (a conditional around the prefetch makes hipcc wait for ALL LDS reads at the
-    // join, i.e. in front of the MFMAs); the last stages run through the guarded form.
-    auto stage_full = [&](int s, const Frags &fc, Frags &fn) {
-        issue_stage(s + 2, (s + 2) % NBUF);
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        lds_barrier();
-        read_frags((s + 1) % NBUF, fn);
-        // MFMAs are register-only: unpinned, hipcc hoists them above the barrier, and the next stage's MFMAs then sit
-        // right behind their own reads.  An empty asm that "modifies" every accumulator pins them behind the reads
-        // (sched_barrier does too, but drives the register allocator into 500 spills here).
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(acc[i][j]));
-        mma_frags(fc);
-    };
-    int s = 0;
-    for (; s + 3 < nst; s += 2) {
-        stage_full(s, f0, f1);
-        stage_full(s + 1, f1, f0);
-    }
-    for (; s < nst; s += 2) {
-        stage(s, f0, f1);
-        if (s + 1 < nst) stage(s + 1, f1, f0);
-    }
-    lds_barrier();  // the epilogue's LDS patch aliases the stage buffers
+#ifdef PHONLP_ABLATION
     if (a.dbg == 2) {  // timing only: keep the accumulators alive without the epilogue
         float t = 0.f;
 #pragma unroll
@@ -515,128 +424,7 @@ __global__ __launch_bounds__(256, 2) void linear_f16x3_dma_kernel(LinearArgs a) 
         if (t == 1234.5f) a.Y[tid] = t;
         return;
     }
-    if (a.rows4 == 2) {
-        at_heads_epilogue<TM, TN>(acc, a, m0, n0, wm, wn, lane);
-        return;
-    }
-    if (a.rows4) {
-        rows4_epilogue<TM, TN>(acc, a, m0, n0, wm, wn, lane);
-        return;
-    }
-    linear_epilogue<TM, TN, WM, WN>(acc, reinterpret_cast<float *>(lds), a, m0, n0, wm, wn, lane, wave);
-}
-
-// The same kernel with the fragments read at the top of their own stage (no register prefetch, 196 VGPRs): used for
-// short K (launch_linear_f16x3).
-template <int TAG>
-__global__ __launch_bounds__(256, 2) void linear_f16x3_dma_np_kernel(LinearArgs a) {
-    constexpr int BM = 256, BN = 128, WM = 2, WN = 2, TM = 4, TN = 2, NBUF = 3;
-    constexpr int ROWS = BM + BN, BUF = ROWS * 64;
-    static_assert(WM * WN * 32 * (TN * 32 + 4) * 4 <= NBUF * BUF, "epilogue patch must fit");
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int ntiles = a.num_m * a.num_n;
-    const int nst = a.K >> 4;
-    int m0, n0;
-    {
-        const int xg = blockIdx.x & 7, jl = blockIdx.x >> 3;
-        const int q = ntiles >> 3, r = ntiles & 7;
-        const int t = (xg < r ? xg * (q + 1) : r * (q + 1) + (xg - r) * q) + jl;
-        constexpr int GM = 4;
-        const int per_group = GM * a.num_n;
-        const int g = t / per_group;
-        const int first_m = g * GM;
-        const int gsz = (a.num_m - first_m) < GM ? (a.num_m - first_m) : GM;
-        const int in = t - g * per_group;
-        m0 = (first_m + in % gsz) * BM;
-        n0 = (in / gsz) * BN;
-    }
-    // wave-load u = 4q + wave (q = 0..5) fills rows 16u .. 16u+15 of the stage image (A rows 0-255, B rows 256-383)
-    const int lr = lane >> 2, chunk = (lane & 3) ^ ((lane >> 4) & 3);
-    const unsigned char *src[6];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        int row = m0 + 16 * (4 * q + wave) + lr;
-        row = row < a.M ? row : a.M - 1;
-        src[q] = reinterpret_cast<const unsigned char *>(a.X) + (long)row * a.ldx + chunk * 16;
-    }
-#pragma unroll
-    for (int q = 4; q < 6; ++q) {
-        int row = n0 + 16 * (4 * (q - 4) + wave) + lr;
-        row = row < a.N ? row : a.N - 1;
-        src[q] = reinterpret_cast<const unsigned char *>(a.W) + (long)row * a.ldw + chunk * 16;
-    }
-    const unsigned lds0 = (unsigned)(uintptr_t)lds + (unsigned)__builtin_amdgcn_readfirstlane(wave) * 1024u;
-    auto issue_stage = [&](int st, int buf) {
-#pragma unroll
-        for (int q = 0; q < 6; ++q) lds_dma16(src[q] + (long)st * 64, lds0 + (unsigned)(buf * BUF + q * 4096));
-    };
-
-    const int r = lane & 31, hh = lane >> 5;
-    const int sw = (r >> 2) & 3;
-    const int off_h = ((2 * hh) ^ sw) << 4, off_l = ((2 * hh + 1) ^ sw) << 4;
-    const int a_ofs = (wm * 128 + r) * 64;
-    const int b_ofs = (BM + wn * 64 + r) * 64;
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    issue_stage(0, 0);
-    if (nst > 1) {
-        issue_stage(1, 1);
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    int cur = 0;
-    for (int s = 0; s < nst; ++s) {
-        const unsigned char *buf = lds + cur * BUF;
-        const int nxt2 = cur == 0 ? 2 : cur - 1;  // (cur + 2) % 3: last read in iteration s-1, behind that barrier
-        if (s + 2 < nst) issue_stage(s + 2, nxt2);
-        u32x4 ah[TM], al[TM], bh[TN], bl[TN];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            bh[j] = *reinterpret_cast<const u32x4 *>(buf + b_ofs + j * 2048 + off_h);
-            bl[j] = *reinterpret_cast<const u32x4 *>(buf + b_ofs + j * 2048 + off_l);
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            al[i] = *reinterpret_cast<const u32x4 *>(buf + a_ofs + i * 2048 + off_l);
-            ah[i] = *reinterpret_cast<const u32x4 *>(buf + a_ofs + i * 2048 + off_h);
-        }
-#define PHONLP_X3_ROUND(AA, BB)                      \
-    _Pragma("unroll") for (int i = 0; i < TM; ++i)   \
-    _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] = PHONLP_F16_MFMA(AA[i], BB[j], acc[i][j]);
-        PHONLP_X3_ROUND(al, bh)
-        PHONLP_X3_ROUND(ah, bl)
-        PHONLP_X3_ROUND(ah, bh)
-#undef PHONLP_X3_ROUND
-        // stage s+1 (issued one iteration ago) must have landed before anyone reads it; the 6 loads of stage s+2 issued
-        // above may stay in flight
-        if (s + 2 < nst) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        lds_barrier();
-        cur = cur == 2 ? 0 : cur + 1;
-    }
-    if (a.dbg == 2) {  // timing only: keep the accumulators alive without the epilogue
-        float t = 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) t += acc[i][j][e];
-        if (t == 1234.5f) a.Y[tid] = t;
-        return;
-    }
+#endif
     if (a.rows4 == 2) {
         at_heads_epilogue<TM, TN>(acc, a, m0, n0, wm, wn, lane);
         return;
@@ -661,53 +449,44 @@ int launch_linear_f16x3(const char *tag, const void *Xp, long pitch_x, const flo
     if (pad_bias && !sentlens) return fail(PHONLP_ERR_SHAPE, "linear_split: pad_bias needs sentlens");
     LinearArgs a{reinterpret_cast<const float *>(Xp), reinterpret_cast<const float *>(Wp), bias, pad_bias, Y, sentlens,
                  pitch_x, pitch_w, ldy, M, N, K16, L, relu, ceil_div(M, 256), ceil_div(N, 128), x_inv, w_inv};
-    constexpr int LDS = 2 * 384 * 64, LDS_DMA = 3 * 384 * 64;
+    constexpr int LDS_DMA = 3 * 384 * 64;
     static PerDeviceOnce attr_once;
     int attr_dev;
     if (attr_once.pending(&attr_dev)) {
-        if (hipFuncSetAttribute((const void *)linear_f16x3_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess ||
-            hipFuncSetAttribute((const void *)linear_f16x3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess ||
-            hipFuncSetAttribute((const void *)linear_f16x3_dma_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DMA) != hipSuccess ||
-            hipFuncSetAttribute((const void *)linear_f16x3_dma_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DMA) != hipSuccess)
-            return fail(PHONLP_ERR_LAUNCH, "linear_split: cannot raise the dynamic LDS limit");
+        const void *fns[] = {(const void *)linear_f16x3_dma_kernel<0, true>, (const void *)linear_f16x3_dma_kernel<1, true>,
+                             (const void *)linear_f16x3_dma_kernel<0, false>, (const void *)linear_f16x3_dma_kernel<1, false>};
+        for (const void *f : fns)
+            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DMA) != hipSuccess)
+                return fail(PHONLP_ERR_LAUNCH, "linear_split: cannot raise the dynamic LDS limit");
         attr_once.mark(attr_dev);
     }
-    const bool stage_a = tag && !strcmp(tag, "linear:label_stage_a");
-    static const bool reg_staged = getenv("PHONLP_X3_REG_STAGED") != nullptr;  // A/B switch: register-staged loop
+    const bool stage_a = tag && !strcmp(tag, "linear:label_stage_a");  // TAG only names the instantiation for the profiler
+#ifdef PHONLP_ABLATION
     static const int abl = getenv("PHONLP_X3_ABLATION") ? atoi(getenv("PHONLP_X3_ABLATION")) : 0;  // timing only
     a.dbg = abl;
+#endif
     a.rows4 = rows4;
     if (at_heads) {
         a.rows4 = 2;
         a.x2 = at_heads->x2; a.P = at_heads->P; a.ldx2 = at_heads->ldx2;
         a.kpc = at_heads->kpc; a.kpx = at_heads->kpx;
+        a.gm = at_heads->gm;
     }
     if (rows4 == 1 && (sentlens || relu || ((uintptr_t)Y & 15)))
         return fail(PHONLP_ERR_SHAPE, "linear_split: the rows-by-4 output takes no activation / padding mask");
     ProfScope ps(tag, stream);
     const dim3 g(a.num_m * a.num_n);
-    if (reg_staged) {
-        if (stage_a) hipLaunchKernelGGL((linear_f16x3_kernel<1>), g, dim3(256), LDS, stream, a);
-        else hipLaunchKernelGGL((linear_f16x3_kernel<0>), g, dim3(256), LDS, stream, a);
-        return check_launch("linear_f16x3_kernel");
-    }
-    // measured (tools/f16x3_probe.py, one box): the register-prefetch loop wins on long K (W1/W2, K = 868: 0.456 vs
-    // 0.482 ms) and loses on short K (stage A, K = 408: 1.65 vs 1.55 ms, its 256 VGPRs cost the epilogue); K16 picks.
+    // the register-prefetch loop wins on long K (W1/W2 layers), the plain loop on short K (stage A): K16 picks
+    // (PHONLP_X3_PREFETCH=0/1 forces one form, A/B only)
     static const int pf_env = getenv("PHONLP_X3_PREFETCH") ? atoi(getenv("PHONLP_X3_PREFETCH")) : -1;
     const bool prefetch = pf_env >= 0 ? pf_env != 0 : K16 >= 512;
-    if (!prefetch) {
-        static bool np_attr = false;
-        if (!np_attr) {
-            (void)hipFuncSetAttribute((const void *)linear_f16x3_dma_np_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DMA);
-            (void)hipFuncSetAttribute((const void *)linear_f16x3_dma_np_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DMA);
-            np_attr = true;
-        }
-        if (stage_a) hipLaunchKernelGGL((linear_f16x3_dma_np_kernel<1>), g, dim3(256), LDS_DMA, stream, a);
-        else hipLaunchKernelGGL((linear_f16x3_dma_np_kernel<0>), g, dim3(256), LDS_DMA, stream, a);
-        return check_launch("linear_f16x3_dma_np_kernel");
+    if (prefetch) {
+        if (stage_a) hipLaunchKernelGGL((linear_f16x3_dma_kernel<1, true>), g, dim3(256), LDS_DMA, stream, a);
+        else hipLaunchKernelGGL((linear_f16x3_dma_kernel<0, true>), g, dim3(256), LDS_DMA, stream, a);
+    } else {
+        if (stage_a) hipLaunchKernelGGL((linear_f16x3_dma_kernel<1, false>), g, dim3(256), LDS_DMA, stream, a);
+        else hipLaunchKernelGGL((linear_f16x3_dma_kernel<0, false>), g, dim3(256), LDS_DMA, stream, a);
     }
-    if (stage_a) hipLaunchKernelGGL((linear_f16x3_dma_kernel<1>), g, dim3(256), LDS_DMA, stream, a);
-    else hipLaunchKernelGGL((linear_f16x3_dma_kernel<0>), g, dim3(256), LDS_DMA, stream, a);
     return check_launch("linear_f16x3_dma_kernel");
 }
 

@@ -3,6 +3,9 @@ usage: python tools/fused_probe.py [reps]   (PHONLP_X3_ABLATION=1/2: timing-only
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+if os.environ.get("PHONLP_X3_ABLATION"):  # the ablation branches only exist in the -DPHONLP_ABLATION build
+    from phonlp_amd import _lib
+    _lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libphonlp_heads_ablation.so")
 from phonlp_amd import HeadWeights, TaskHeads, ops, synthetic as S
 from phonlp_amd.profile import KernelTimer
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
