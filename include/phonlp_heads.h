@@ -319,6 +319,40 @@ int phonlp_gather_first_subword(const float *enc, const void *first_subword, int
 int phonlp_scatter_rows(const int32_t *src, int B, int Ls, int col0, const int32_t *dest_row, int32_t *dst, int Ld,
                         int n_dst, const int32_t *status_opt, int32_t *fail_count_opt, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Packed rows -- ragged batches without the padding's arithmetic.
+ * The reference runs every dense layer on PackedSequence data, i.e. on the live words only (annotate_model.py:114-130,
+ * 155-170: pack() = pack_padded_sequence, pad() = pad_packed_sequence), and pads again before the biaffine scorers
+ * (:187); the padded tensors it scores (pad_packed_sequence zeros -> relu(b) rows) are constant rows.  Here the same
+ * thing sentence-major: the live words (b, i), i < sentlens[b], of a [B, L, .] tensor are packed one sentence after the
+ * other into m_live = sum(sentlens) rows, every row-wise entry point above (phonlp_pos_head_split, phonlp_tagger_head,
+ * phonlp_linear_split, phonlp_split_rows) is then called with B = 1, L = m_live on the packed rows, and the three entry
+ * points that need the sentence structure take the packing's descriptor:
+ *   off[b]    = sentence b's first packed row (off[B] = m_live; usable as the 1-sentence "sentlens" of those calls),
+ *   rowmap[p] = b*L + i of packed row p.
+ * phonlp_pack_descriptor builds both on the device from sentlens (rowmap holds `cap` >= m_live entries);
+ * phonlp_pack_rows gathers fp32 rows (dst[p] = src[rowmap[p]], W % 4 == 0); phonlp_unpack_rows scatters 4-byte rows back
+ * (dst [n_dst, W] zero-filled first, dst[rowmap[p]] = src[p]): pos_pred / NER emissions of the padding are zeros as in
+ * the unpacked entry points.
+ * phonlp_biaffine_arc_scores_packed = phonlp_biaffine_arc_scores with XF packed; pad_row [n_scorers*2*KP] is the first
+ * layer's output for a padded word (relu of the layer's own bias: the hidden row is zero).  The head columns
+ * j >= sentlens[b] take pad_row, so every live dependent's log-softmax runs over all L columns exactly as in the
+ * unpacked form; the rows of padded dependents are not written (the decoders never read them).
+ * phonlp_label_at_heads_fused_packed = phonlp_label_at_heads_fused with X1p / XF packed; heads / rels / best_opt keep
+ * their [B, L] shape (labels of ROOT and padding 0).  Workspace: phonlp_label_at_heads_fused_ws_bytes(1, m_live, H, O)
+ * resp. phonlp_biaffine_arc_scores_ws_bytes(1, m_live, H, n_scorers). */
+int phonlp_pack_descriptor(const int32_t *sentlens, int B, int L, int32_t *off, int32_t *rowmap, int cap, void *stream);
+int phonlp_pack_rows(const float *src, int ld_src, int n_src, const int32_t *rowmap, int m, int W, float *dst, void *stream);
+int phonlp_unpack_rows(const void *src, const int32_t *rowmap, int m, int W, void *dst, int n_dst, void *stream);
+int phonlp_biaffine_arc_scores_packed(const float *XF, int m_live, const int32_t *off, const int32_t *sentlens,
+                                      const float *pad_row, int B, int L, int H, int n_scorers, int use_lin, int use_dist,
+                                      const float *Wbt, float *arc_logp, float *raw_opt, void *ws, size_t ws_bytes,
+                                      void *stream);
+int phonlp_label_at_heads_fused_packed(const void *X1p, const float *x1_inv, const void *Wbtcp, const float *wbtc_inv,
+                                       const float *XF, const int32_t *heads, const int32_t *sentlens,
+                                       const int32_t *rowmap, const int32_t *off, int m_live, int B, int L, int H, int O,
+                                       int32_t *rels, float *best_opt, void *ws, size_t ws_bytes, void *stream);
+
 /* Eval counts -- what the reference's scorers accumulate per corpus (models/pos/scorer.py:29-36 POS accuracy;
  * utils/conll18_ud_eval.py:531-532 UAS/LAS; tag-level NER agreement).  ADDS to counts[0..7] (int64, device):
  * sentences, words, pos_correct, ner_correct, uas_correct, las_correct, mst_failures, 0.  Tagger tensors are

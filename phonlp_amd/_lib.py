@@ -58,6 +58,11 @@ SIGNATURES = {
     "phonlp_gather_labels": (_i, [_p, _p, _p, _i, _i, _p, _p]),
     "phonlp_gather_first_subword": (_i, [_p, _p, _i, _p, _i, _i, _i, _i, _p, _p]),
     "phonlp_scatter_rows": (_i, [_p, _i, _i, _i, _p, _p, _i, _i, _p, _p, _p]),
+    "phonlp_pack_descriptor": (_i, [_p, _i, _i, _p, _p, _i, _p]),
+    "phonlp_pack_rows": (_i, [_p, _i, _i, _p, _i, _i, _p, _p]),
+    "phonlp_unpack_rows": (_i, [_p, _p, _i, _i, _p, _i, _p]),
+    "phonlp_biaffine_arc_scores_packed": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _z, _p]),
+    "phonlp_label_at_heads_fused_packed": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _z, _p]),
     "phonlp_eval_counts": (_i, [_p] * 11 + [_i, _i, _i, _p, _p]),
     "phonlp_dep_loss_ws_bytes": (_z, [_i, _i]),
     "phonlp_dep_loss": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, ctypes.c_float, _p, _p, _z, _p]),

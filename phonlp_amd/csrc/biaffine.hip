@@ -27,7 +27,28 @@ struct ArcArgs {
     long ldT, ldx;
     int B, L, KP, S, LP;
     int use_lin, use_dist;
+    // ragged batches packed (phonlp_biaffine_arc_scores_packed): T / XF hold only the live words, sentence b's at rows
+    // off[b] .. off[b] + sentlens[b]; a padded head column reads the one row `pad` (what the first layer gives a zero
+    // hidden row) and padded dependents are not scored at all (their rows of `out` stay untouched)
+    const int32_t *off, *sentlens;
+    const float *pad;
 };
+
+// slab_load with the rows from `live` on taken from the single row `pad` (a padded head's features)
+template <int ROWS, int THREADS>
+__device__ __forceinline__ void slab_load_pad(Slab<ROWS, THREADS> &s, const float *base, long ld, int rows_valid, int live,
+                                              const float *pad, int k0, int K, int tid) {
+#pragma unroll
+    for (int q = 0; q < Slab<ROWS, THREADS>::N; ++q) {
+        const int idx = tid + q * THREADS;
+        const int row = idx >> 3;
+        const int c4 = (idx & 7) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float *rp = row < live ? base + (long)row * ld : pad;
+        if (row < rows_valid && k0 + c4 < K) v = *reinterpret_cast<const float4 *>(rp + k0 + c4);
+        s.v[q] = v;
+    }
+}
 
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
@@ -97,15 +118,18 @@ __global__ __launch_bounds__(256) void arc_kernel(ArcArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y, i0 = blockIdx.x * 32;
     const int L = a.L, KP = a.KP, LP = a.LP;
-    const int iv = L - i0;
+    const int len = a.off ? min(max(a.sentlens[b], 0), L) : L;
+    if (i0 >= len) return;  // packed: nothing but padded dependents here (block-uniform)
+    const long rowbase = a.off ? a.off[b] : (long)b * L;
+    const int iv = len - i0;
     const int nk = (KP + BK - 1) / BK;
     const int total = a.S * nk;
-    const float *Tb = a.T + ((long)b * L + i0) * a.ldT;
+    const float *Tb = a.T + (rowbase + i0) * a.ldT;
     const long plane = (long)a.B * L * L;
 
     for (int j0 = 0; j0 < L; j0 += 128) {
-        const int jv = L - j0;
-        const float *Xb = a.XF + ((long)b * L + j0) * a.ldx;
+        const int jv = L - j0, jl = len - j0;
+        const float *Xb = a.XF + (rowbase + j0) * a.ldx;
         f32x16 acc0[1][1], acc1[1][1], acc2[1][1];
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc0[0][0][r] = acc1[0][0][r] = acc2[0][0][r] = 0.f;
@@ -113,7 +137,7 @@ __global__ __launch_bounds__(256) void arc_kernel(ArcArgs a) {
         Slab<32, 256> ra;
         Slab<128, 256> rb;
         slab_load(ra, Tb, a.ldT, iv, 0, KP, tid);
-        slab_load(rb, Xb + KP, a.ldx, jv, 0, KP, tid);
+        slab_load_pad(rb, Xb + KP, a.ldx, jv, jl, a.pad + KP, 0, KP, tid);
         __syncthreads();  // previous column group / softmax phase done with the staging buffers
         slab_store(ra, As, tid);
         slab_store(rb, Bs, tid);
@@ -123,7 +147,7 @@ __global__ __launch_bounds__(256) void arc_kernel(ArcArgs a) {
             if (it + 1 < total) {
                 const int s2 = (it + 1) / nk, k2 = ((it + 1) % nk) * BK;
                 slab_load(ra, Tb + s2 * KP, a.ldT, iv, k2, KP, tid);
-                slab_load(rb, Xb + (2 * s2 + 1) * KP, a.ldx, jv, k2, KP, tid);
+                slab_load_pad(rb, Xb + (2 * s2 + 1) * KP, a.ldx, jv, jl, a.pad + (2 * s2 + 1) * KP, k2, KP, tid);
             }
             const float *Bw = Bs + wave * 32 * PITCH;
             const int depth = slab_depth((it - s * nk) * BK, KP);
@@ -201,15 +225,18 @@ __global__ __launch_bounds__(256) void arc_kernel128(ArcArgs a) {
     float *patch = smem + (ROWS + 128) * PITCH + wave * 32 * 33;
     const int b = blockIdx.y, i0 = blockIdx.x * ROWS;
     const int L = a.L, KP = a.KP, LP = a.LP;
-    const int iv = L - i0;
+    const int len = a.off ? min(max(a.sentlens[b], 0), L) : L;
+    if (i0 >= len) return;  // packed: nothing but padded dependents here (block-uniform)
+    const long rowbase = a.off ? a.off[b] : (long)b * L;
+    const int iv = len - i0;
     const int nk = (KP + BK - 1) / BK;
     const int total = a.S * nk;
-    const float *Tb = a.T + ((long)b * L + i0) * a.ldT;
+    const float *Tb = a.T + (rowbase + i0) * a.ldT;
     const long plane = (long)a.B * L * L;
 
     for (int j0 = 0; j0 < L; j0 += 128) {
-        const int jv = L - j0;
-        const float *Xb = a.XF + ((long)b * L + j0) * a.ldx;
+        const int jv = L - j0, jl = len - j0;
+        const float *Xb = a.XF + (rowbase + j0) * a.ldx;
         f32x16 acc[TMW][2];
 #pragma unroll
         for (int i = 0; i < TMW; ++i)
@@ -221,7 +248,7 @@ __global__ __launch_bounds__(256) void arc_kernel128(ArcArgs a) {
         Slab<ROWS, 256> ra;
         Slab<128, 256> rb;
         slab_load(ra, Tb, a.ldT, iv, 0, KP, tid);
-        slab_load(rb, Xb + KP, a.ldx, jv, 0, KP, tid);
+        slab_load_pad(rb, Xb + KP, a.ldx, jv, jl, a.pad + KP, 0, KP, tid);
         __syncthreads();  // previous column group done with the staging buffers
         slab_store(ra, As, tid);
         slab_store(rb, Bs, tid);
@@ -231,7 +258,7 @@ __global__ __launch_bounds__(256) void arc_kernel128(ArcArgs a) {
             if (it + 1 < total) {
                 const int s2 = kk + 1 == nk ? s + 1 : s, k2 = (kk + 1 == nk ? 0 : kk + 1) * BK;
                 slab_load(ra, Tb + s2 * KP, a.ldT, iv, k2, KP, tid);
-                slab_load(rb, Xb + (2 * s2 + 1) * KP, a.ldx, jv, k2, KP, tid);
+                slab_load_pad(rb, Xb + (2 * s2 + 1) * KP, a.ldx, jv, jl, a.pad + (2 * s2 + 1) * KP, k2, KP, tid);
             }
             const float *Aw = As + wm * (ROWS / 2) * PITCH, *Bw = Bs + wn * 64 * PITCH;
             mma_slab<TMW, 2, ENG>(Aw, Bw, lane, acc, slab_depth(kk * BK, KP));
@@ -583,8 +610,9 @@ extern "C" int phonlp_kp(int H) { return kp_of(H); }
 
 // stage A of the 1 or 3 arc scorers + the arc kernel, from the scorers' features XF [M, S*2*KP]
 static int arc_from_features(const float *XF, float *T, int B, int L, int KP, int S, int use_lin, int use_dist,
-                             const float *Wbt, float *arc_logp, float *raw_opt, hipStream_t st) {
-    const int M = B * L;
+                             const float *Wbt, float *arc_logp, float *raw_opt, hipStream_t st, int m_live = 0,
+                             const int32_t *off = nullptr, const int32_t *sentlens = nullptr, const float *pad = nullptr) {
+    const int M = off ? m_live : B * L;
     int rc;
     // stage A of the S scorers as ONE batched launch (item s: X1 of scorer s, its bilinear weight, its slice of T).
     // Engine 1 under engine 2 as well: running it on the f16x3 kernel was measured (the GEMM 0.20 -> 0.16 ms at B=256,
@@ -592,7 +620,7 @@ static int arc_from_features(const float *XF, float *T, int B, int L, int KP, in
     rc = launch_linear("linear:arc_stage_a", XF, (long)S * 2 * KP, Wbt, KP, nullptr, T, (long)S * KP, M, KP, KP, 0, nullptr, 0,
                        st, nullptr, S, 2L * KP, (long)KP * KP, KP);
     if (rc) return rc;
-    ArcArgs a{T, XF, arc_logp, raw_opt, (long)S * KP, (long)S * 2 * KP, B, L, KP, S, 0, use_lin, use_dist};
+    ArcArgs a{T, XF, arc_logp, raw_opt, (long)S * KP, (long)S * 2 * KP, B, L, KP, S, 0, use_lin, use_dist, off, sentlens, pad};
     a.LP = (L + 31) / 32 * 32 + 1;
     const size_t lds = (size_t)(160 * PITCH + 32 * a.LP) * sizeof(float);
     static PerDeviceOnce attr_once;
@@ -675,6 +703,26 @@ extern "C" int phonlp_biaffine_arc_scores(const float *XF, int B, int L, int H, 
         return fail(PHONLP_ERR_WORKSPACE, "biaffine_arc_scores: workspace too small");
     return arc_from_features(XF, (float *)ws, B, L, kp_of(H), n_scorers, use_lin, use_dist, Wbt, arc_logp, raw_opt,
                              as_stream(stream));
+}
+
+/* The same for a ragged batch whose live words are packed (sentence b's rows at off[b] .. off[b] + sentlens[b] of XF). */
+extern "C" int phonlp_biaffine_arc_scores_packed(const float *XF, int m_live, const int32_t *off, const int32_t *sentlens,
+                                                 const float *pad_row, int B, int L, int H, int n_scorers, int use_lin,
+                                                 int use_dist, const float *Wbt, float *arc_logp, float *raw_opt, void *ws,
+                                                 size_t ws_bytes, void *stream) {
+    if (!XF || !Wbt || !arc_logp || !off || !sentlens || !pad_row || B <= 0 || L <= 0 || H <= 0 || m_live <= 0 ||
+        (long)m_live > (long)B * L)
+        return fail(PHONLP_ERR_SHAPE, "biaffine_arc_scores_packed: bad argument");
+    if (n_scorers != 1 && n_scorers != 3) return fail(PHONLP_ERR_SHAPE, "biaffine_arc_scores_packed: n_scorers must be 1 or 3");
+    if (n_scorers == 1 && (use_lin || use_dist))
+        return fail(PHONLP_ERR_SHAPE, "biaffine_arc_scores_packed: use_lin/use_dist need n_scorers == 3");
+    if (L > 1024) return fail(PHONLP_ERR_UNSUPPORTED, "biaffine_arc_scores_packed: L > 1024 does not fit the LDS row buffer");
+    if (((uintptr_t)XF & 15) || ((uintptr_t)pad_row & 15))
+        return fail(PHONLP_ERR_SHAPE, "biaffine_arc_scores_packed: XF, pad_row must be 16-byte aligned");
+    if (ws_bytes < align_up((size_t)m_live * n_scorers * kp_of(H) * sizeof(float), 256) || !ws)
+        return fail(PHONLP_ERR_WORKSPACE, "biaffine_arc_scores_packed: workspace too small");
+    return arc_from_features(XF, (float *)ws, B, L, kp_of(H), n_scorers, use_lin, use_dist, Wbt, arc_logp, raw_opt,
+                             as_stream(stream), m_live, off, sentlens, pad_row);
 }
 
 extern "C" size_t phonlp_biaffine_label_ws_bytes(int B, int L, int H, int O) {

@@ -143,9 +143,93 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const int32_t *src, i
     }
 }
 
+// ---- ragged batches: the live rows (b, i), i < sentlens[b], of a [B, L, .] tensor packed one sentence after the other.
+// off[b] = sum of sentlens[0..b) (off[B] = number of live rows), rowmap[off[b] + i] = b*L + i.  One block per sentence;
+// every block sums the lengths before its own (B is a few thousand at most).
+__global__ __launch_bounds__(256) void pack_descriptor_kernel(const int32_t *sentlens, int B, int L, int32_t *off,
+                                                              int32_t *rowmap, int cap) {
+    __shared__ int part[256];
+    const int b = blockIdx.x;
+    int s = 0;
+    for (int k = threadIdx.x; k < b; k += 256) {
+        const int l = sentlens[k];
+        s += l < 0 ? 0 : (l > L ? L : l);
+    }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+        __syncthreads();
+    }
+    const int o0 = part[0];
+    if (b == B) {  // the extra block only writes the total
+        if (threadIdx.x == 0) off[B] = o0;
+        return;
+    }
+    int len = sentlens[b];
+    len = len < 0 ? 0 : (len > L ? L : len);
+    if (threadIdx.x == 0) off[b] = o0;
+    for (int i = threadIdx.x; i < len; i += 256)
+        if (o0 + i < cap) rowmap[o0 + i] = b * L + i;
+}
+
+// dst[p][0..W) = src[rowmap[p]][0..W) (fp32 rows, W % 4 == 0): one wavefront per row
+__global__ __launch_bounds__(256) void pack_rows_kernel(const float *src, long ld_src, const int32_t *rowmap, int m, int W,
+                                                        int n_src, float *dst) {
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (p >= m) return;
+    const int r = rowmap[p];
+    if (r < 0 || r >= n_src) return;
+    const float *s = src + (long)r * ld_src;
+    float *d = dst + (long)p * W;
+    for (int c = lane * 4; c < W; c += 256) *reinterpret_cast<float4 *>(d + c) = *reinterpret_cast<const float4 *>(s + c);
+}
+
+// dst[rowmap[p]][0..W) = src[p][0..W) for 4-byte elements (dst zeroed by the caller beforehand)
+__global__ __launch_bounds__(256) void unpack_rows_kernel(const uint32_t *src, const int32_t *rowmap, int m, int W, int n_dst,
+                                                          uint32_t *dst) {
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < (long)m * W; idx += (long)gridDim.x * blockDim.x) {
+        const int p = (int)(idx / W), c = (int)(idx - (long)p * W);
+        const int r = rowmap[p];
+        if (r >= 0 && r < n_dst) dst[(long)r * W + c] = src[idx];
+    }
+}
+
 }  // namespace phonlp
 
 using namespace phonlp;
+
+extern "C" int phonlp_pack_descriptor(const int32_t *sentlens, int B, int L, int32_t *off, int32_t *rowmap, int cap,
+                                      void *stream) {
+    if (!sentlens || !off || !rowmap || B <= 0 || L <= 0 || cap <= 0)
+        return fail(PHONLP_ERR_SHAPE, "pack_descriptor: bad argument");
+    ProfScope ps("pack_descriptor", as_stream(stream));
+    hipLaunchKernelGGL(pack_descriptor_kernel, dim3(B + 1), dim3(256), 0, as_stream(stream), sentlens, B, L, off, rowmap, cap);
+    return check_launch("pack_descriptor_kernel");
+}
+
+extern "C" int phonlp_pack_rows(const float *src, int ld_src, int n_src, const int32_t *rowmap, int m, int W, float *dst,
+                                void *stream) {
+    if (!src || !rowmap || !dst || m <= 0 || W <= 0 || n_src <= 0) return fail(PHONLP_ERR_SHAPE, "pack_rows: bad argument");
+    if ((W & 3) || (ld_src & 3) || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15))
+        return fail(PHONLP_ERR_SHAPE, "pack_rows: W, ld_src must be multiples of 4 and src, dst 16-byte aligned");
+    ProfScope ps("pack_rows", as_stream(stream));
+    hipLaunchKernelGGL(pack_rows_kernel, dim3((m + 3) / 4), dim3(256), 0, as_stream(stream), src, (long)ld_src, rowmap, m, W,
+                       n_src, dst);
+    return check_launch("pack_rows_kernel");
+}
+
+extern "C" int phonlp_unpack_rows(const void *src, const int32_t *rowmap, int m, int W, void *dst, int n_dst, void *stream) {
+    if (!src || !rowmap || !dst || m <= 0 || W <= 0 || n_dst <= 0) return fail(PHONLP_ERR_SHAPE, "unpack_rows: bad argument");
+    hipStream_t st = as_stream(stream);
+    ProfScope ps("unpack_rows", st);
+    if (hipMemsetAsync(dst, 0, (size_t)n_dst * W * 4, st) != hipSuccess)
+        return fail(PHONLP_ERR_LAUNCH, "unpack_rows: hipMemsetAsync failed");
+    const long work = (long)m * W;
+    hipLaunchKernelGGL(unpack_rows_kernel, dim3((unsigned)((work + 255) / 256 < 2048 ? (work + 255) / 256 : 2048)), dim3(256), 0,
+                       st, (const uint32_t *)src, rowmap, m, W, n_dst, (uint32_t *)dst);
+    return check_launch("unpack_rows_kernel");
+}
 
 extern "C" int phonlp_scatter_rows(const int32_t *src, int B, int Ls, int col0, const int32_t *dest_row, int32_t *dst,
                                    int Ld, int n_dst, const int32_t *status_opt, int32_t *fail_count_opt, void *stream) {

@@ -182,7 +182,8 @@ __device__ __forceinline__ void at_heads_epilogue(f32x16 (&acc)[TM][TN], const L
 // transposed so that the epilogue above reads them word-contiguous.  Block = 32 words x 32 features through LDS.
 __global__ __launch_bounds__(1024) void gather_heads_t_kernel(const int32_t *heads, const int32_t *sentlens,
                                                               const float *x2, long ldx2, int M, int L, int kpx,
-                                                              int32_t *hrow, float *x2t) {
+                                                              int32_t *hrow, float *x2t, const int32_t *rowmap,
+                                                              const int32_t *off) {
     __shared__ float tile[32][33];
     __shared__ int hr[32];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -191,10 +192,12 @@ __global__ __launch_bounds__(1024) void gather_heads_t_kernel(const int32_t *hea
         const int m = m0 + tx;
         int v = -1;
         if (m < M) {
-            const int b = m / L, i = m - b * L;
+            // packed (rowmap != NULL): word m is the live word rowmap[m] = b*L + i, its head's features are row off[b] + h
+            const int dm = rowmap ? rowmap[m] : m;
+            const int b = dm / L, i = dm - b * L;
             if (i >= 1 && i < sentlens[b]) {
-                const int h = heads[m];
-                if (h >= 0 && h < L) v = b * L + h;
+                const int h = heads[dm];
+                if (h >= 0 && h < (rowmap ? sentlens[b] : L)) v = (rowmap ? off[b] : b * L) + h;
             }
             if (blockIdx.y == 0) hrow[m] = v;
         }
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(1024) void gather_heads_t_kernel(const int32_t *hea
 // rels[m] = argmax_o sum_{t < gpo} P[o*gpo + t][m] (shares added in ascending t; strict '>' in ascending o), 0 for
 // words without a label.  Block = 64 words x 8 relation classes (o mod 8), combined through LDS.
 __global__ __launch_bounds__(512) void label_reduce_kernel(const float *P, const int32_t *hrow, int M, int O, int gpo,
-                                                           int32_t *rels, float *best_opt) {
+                                                           int32_t *rels, float *best_opt, const int32_t *rowmap) {
     __shared__ float sv[8][64];
     __shared__ int so[8][64];
     const int lx = threadIdx.x & 63, oq = threadIdx.x >> 6;
@@ -230,8 +233,9 @@ __global__ __launch_bounds__(512) void label_reduce_kernel(const float *P, const
     if (oq == 0 && m < M) {
         for (int q = 1; q < 8; ++q)
             if (sv[q][lx] > bv || (sv[q][lx] == bv && so[q][lx] < bo)) { bv = sv[q][lx]; bo = so[q][lx]; }
-        rels[m] = live && bo != INT_MAX ? bo : 0;
-        if (best_opt) best_opt[m] = live && bo != INT_MAX ? bv : 0.f;
+        const int dm = rowmap ? rowmap[m] : m;  // packed: the caller zeroed rels / best_opt, the live words are scattered
+        rels[dm] = live && bo != INT_MAX ? bo : 0;
+        if (best_opt) best_opt[dm] = live && bo != INT_MAX ? bv : 0.f;
     }
 }
 
@@ -557,23 +561,23 @@ extern "C" size_t phonlp_label_at_heads_fused_ws_bytes(int B, int L, int H, int 
            align_up((size_t)kp_of(H) * M * sizeof(float), 256);
 }
 
-extern "C" int phonlp_label_at_heads_fused(const void *X1p, const float *x1_inv, const void *Wbtcp, const float *wbtc_inv,
-                                           const float *XF, const int32_t *heads, const int32_t *sentlens, int B, int L,
-                                           int H, int O, int32_t *rels, float *best_opt, void *ws, size_t ws_bytes,
-                                           void *stream) {
-    if (!X1p || !x1_inv || !Wbtcp || !wbtc_inv || !XF || !heads || !sentlens || !rels || B <= 0 || L <= 0 || H <= 0 || O <= 0)
-        return fail(PHONLP_ERR_SHAPE, "label_at_heads_fused: bad argument");
-    if (!ws || ws_bytes < phonlp_label_at_heads_fused_ws_bytes(B, L, H, O))
-        return fail(PHONLP_ERR_WORKSPACE, "label_at_heads_fused: workspace too small");
-    hipStream_t st = as_stream(stream);
-    const int M = B * L, KP = kp_of(H), K16 = (KP + 15) / 16 * 16, KPC = phonlp_label_kpc(H);
+static int label_at_heads_fused_run(const void *X1p, const float *x1_inv, const void *Wbtcp, const float *wbtc_inv,
+                                    const float *XF, const int32_t *heads, const int32_t *sentlens, int B, int L, int M,
+                                    const int32_t *rowmap, const int32_t *off, int H, int O, int32_t *rels,
+                                    float *best_opt, void *ws, hipStream_t st) {
+    const int KP = kp_of(H), K16 = (KP + 15) / 16 * 16, KPC = phonlp_label_kpc(H);
     int32_t *hrow = (int32_t *)ws;
     float *P = (float *)((char *)ws + align_up((size_t)M * sizeof(int32_t), 256));
     float *x2t = (float *)((char *)P + align_up((size_t)O * (KPC / 32) * M * sizeof(float), 256));
+    if (rowmap) {  // ROOT and padding keep label 0
+        if (hipMemsetAsync(rels, 0, (size_t)B * L * sizeof(int32_t), st) != hipSuccess ||
+            (best_opt && hipMemsetAsync(best_opt, 0, (size_t)B * L * sizeof(float), st) != hipSuccess))
+            return fail(PHONLP_ERR_LAUNCH, "label_at_heads_fused_packed: hipMemsetAsync failed");
+    }
     {
         ProfScope ps("gather_heads_t", st);
         hipLaunchKernelGGL(gather_heads_t_kernel, dim3(ceil_div(M, 32), ceil_div(KP, 32)), dim3(1024), 0, st, heads, sentlens,
-                           XF + KP, 2L * KP, M, L, KP, hrow, x2t);
+                           XF + KP, 2L * KP, M, L, KP, hrow, x2t, rowmap, off);
         const int rc = check_launch("gather_heads_t_kernel");
         if (rc) return rc;
     }
@@ -584,6 +588,35 @@ extern "C" int phonlp_label_at_heads_fused(const void *X1p, const float *x1_inv,
                                  0, O * KPC, M, K16, 0, nullptr, 0, st, nullptr, 0, &ah);
     if (rc) return rc;
     ProfScope ps("label_reduce", st);
-    hipLaunchKernelGGL(label_reduce_kernel, dim3(ceil_div(M, 64)), dim3(512), 0, st, P, hrow, M, O, KPC / 32, rels, best_opt);
+    hipLaunchKernelGGL(label_reduce_kernel, dim3(ceil_div(M, 64)), dim3(512), 0, st, P, hrow, M, O, KPC / 32, rels, best_opt,
+                       rowmap);
     return check_launch("label_reduce_kernel");
+}
+
+extern "C" int phonlp_label_at_heads_fused(const void *X1p, const float *x1_inv, const void *Wbtcp, const float *wbtc_inv,
+                                           const float *XF, const int32_t *heads, const int32_t *sentlens, int B, int L,
+                                           int H, int O, int32_t *rels, float *best_opt, void *ws, size_t ws_bytes,
+                                           void *stream) {
+    if (!X1p || !x1_inv || !Wbtcp || !wbtc_inv || !XF || !heads || !sentlens || !rels || B <= 0 || L <= 0 || H <= 0 || O <= 0)
+        return fail(PHONLP_ERR_SHAPE, "label_at_heads_fused: bad argument");
+    if (!ws || ws_bytes < phonlp_label_at_heads_fused_ws_bytes(B, L, H, O))
+        return fail(PHONLP_ERR_WORKSPACE, "label_at_heads_fused: workspace too small");
+    return label_at_heads_fused_run(X1p, x1_inv, Wbtcp, wbtc_inv, XF, heads, sentlens, B, L, B * L, nullptr, nullptr, H, O,
+                                    rels, best_opt, ws, as_stream(stream));
+}
+
+/* The same for a ragged batch whose live words are packed: X1p / XF hold m_live rows (rowmap[p] = b*L + i of packed row p,
+ * off[b] = sentence b's first packed row); heads, rels, best_opt stay [B, L].  Workspace: the dense size for (1, m_live). */
+extern "C" int phonlp_label_at_heads_fused_packed(const void *X1p, const float *x1_inv, const void *Wbtcp,
+                                                  const float *wbtc_inv, const float *XF, const int32_t *heads,
+                                                  const int32_t *sentlens, const int32_t *rowmap, const int32_t *off,
+                                                  int m_live, int B, int L, int H, int O, int32_t *rels, float *best_opt,
+                                                  void *ws, size_t ws_bytes, void *stream) {
+    if (!X1p || !x1_inv || !Wbtcp || !wbtc_inv || !XF || !heads || !sentlens || !rowmap || !off || !rels || B <= 0 || L <= 0 ||
+        H <= 0 || O <= 0 || m_live <= 0 || (long)m_live > (long)B * L)
+        return fail(PHONLP_ERR_SHAPE, "label_at_heads_fused_packed: bad argument");
+    if (!ws || ws_bytes < phonlp_label_at_heads_fused_ws_bytes(1, m_live, H, O))
+        return fail(PHONLP_ERR_WORKSPACE, "label_at_heads_fused_packed: workspace too small");
+    return label_at_heads_fused_run(X1p, x1_inv, Wbtcp, wbtc_inv, XF, heads, sentlens, B, L, m_live, rowmap, off, H, O, rels,
+                                    best_opt, ws, as_stream(stream));
 }

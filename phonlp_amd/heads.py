@@ -194,8 +194,13 @@ class TaskHeads:
             "ones_col": env("PHONLP_ONES_COL", "1") == "1",      # unfused form: X1's ones column as a per-column bias
             # stage A fused with labels-at-heads behind the MST (T never reaches HBM): default since the round-based MST
             "label_fused": env("PHONLP_LABEL_FUSED", "1") == "1",
+            # ragged batches whose lengths the host knows: the live words packed (no arithmetic on padding); 0 = off,
+            # else the largest live fraction (percent) that is still packed
+            "pack_pct": int(env("PHONLP_PACK", "90")),
         }
         self._side = None
+        # what the arc scorers' first layer gives a padded word (zero hidden row): relu of the layer's own bias
+        self._arc_pad_row = torch.relu(weights.arc_b12).contiguous()
 
     # ---- JointModel.tagger_forward after the gather (ref annotate_model.py:132-152)
     def tagger(self, enc: torch.Tensor, sentlens) -> Dict[str, torch.Tensor]:
@@ -274,6 +279,33 @@ class TaskHeads:
         gd = None if gold is None else gold.to(device=dev, dtype=torch.int32).contiguous()
         return ops.crf_log_partition(ner_logits.contiguous(), self.w.trans, pm, ln, gd)
 
+    def _pack_plan(self, enc_dep, sentlens_dep, enc_tag, sentlens_tag):
+        """(live parser words, live tagger words) when this batch runs packed, else None.  Packed: engine 2 with its
+        default fused / folded label path, sentence lengths known to the HOST (a list / CPU tensor: the live row count
+        sizes every launch, and reading it from a device tensor would stall the stream), every sentence non-empty,
+        and enough padding to pay for the gather (cfg pack_pct)."""
+        cfg, w = self.cfg, self.w
+        if not cfg["pack_pct"] or ops.get_gemm_engine() != 2 or w.lab_Wbt_s is None:
+            return None
+        if not (cfg["label_fused"] and cfg["pos_fold"] and w.arc_W12p_s is not None and cfg["tagger_fused"]):
+            return None
+
+        def host(l):
+            if isinstance(l, torch.Tensor):
+                return None if l.is_cuda else [int(v) for v in l.tolist()]
+            return [int(v) for v in l]
+
+        ld, lt = host(sentlens_dep), host(sentlens_tag)
+        if ld is None or lt is None:
+            return None
+        Ld, Lt = enc_dep.shape[1], enc_tag.shape[1]
+        if min(ld) < 1 or min(lt) < 1 or max(ld) > Ld or max(lt) > Lt:
+            return None
+        md, mt = sum(ld), sum(lt)
+        if 100 * md > cfg["pack_pct"] * len(ld) * Ld:
+            return None
+        return md, mt
+
     # ---- the whole head path for one batch: what annotate() needs per batch (ref :256-287)
     def annotate_batch(self, enc_dep, sentlens_dep, enc_tag, sentlens_tag, overlap=True,
                        join=True) -> Dict[str, torch.Tensor]:
@@ -305,6 +337,7 @@ class TaskHeads:
             self._side = (torch.cuda.Stream(priority=cfg["tag_prio"]), torch.cuda.Stream(priority=cfg["mst_prio"]),
                           torch.cuda.Stream())
         s_tag, s_mst, s_fin = self._side
+        pack = self._pack_plan(enc_dep, sentlens_dep, enc_tag, sentlens_tag)
         lens_d = as_sentlens(sentlens_dep, enc_dep.device)
         lens_t = as_sentlens(sentlens_tag, enc_tag.device)
         # tagger chain on its own stream
@@ -313,7 +346,15 @@ class TaskHeads:
             for t in (enc_tag, lens_t):  # the caller may drop its batch while the side stream still reads it
                 t.record_stream(s_tag)
             with torch.cuda.stream(s_tag):
-                if cfg["tagger_fused"]:
+                if pack:  # the tagger head on the live words only; its two outputs scattered back (zeros on padding)
+                    Bt, Lt = enc_tag.shape[0], enc_tag.shape[1]
+                    off_t, map_t = ops.pack_descriptor(lens_t, Lt, pack[1])
+                    encp = ops.pack_rows(enc_tag.reshape(Bt * Lt, -1), map_t)
+                    pos_p, ner_p, _ = ops.tagger_head(encp.view(1, pack[1], -1), off_t[Bt:], w.tag_Whn, w.tag_bhn,
+                                                      w.upos_clf_w, w.upos_clf_b, w.emb_ner, w.ner_w_emb, w.ner_b)
+                    tag = {"pos_pred": ops.unpack_rows(pos_p.view(-1), map_t, Bt * Lt).view(Bt, Lt),
+                           "ner_logits": ops.unpack_rows(ner_p.view(pack[1], -1), map_t, Bt * Lt).view(Bt, Lt, -1)}
+                elif cfg["tagger_fused"]:
                     pos_pred, ner_logits, _ = ops.tagger_head(enc_tag.contiguous(), lens_t, w.tag_Whn, w.tag_bhn,
                                                               w.upos_clf_w, w.upos_clf_b, w.emb_ner, w.ner_w_emb, w.ner_b)
                     tag = {"pos_pred": pos_pred, "ner_logits": ner_logits}
@@ -345,11 +386,25 @@ class TaskHeads:
                 # the embedding is folded into the scorers' weights: the "feat" image is [enc | tag probabilities]
                 emb, arcW, labW = w.emb_eye, w.arc_W12p_s, w.lab_W12p_s
                 D = enc_dep.shape[2] + emb.shape[1]
-            featp, feati, _, _, _ = ops.pos_head_split(enc_dep.contiguous(), lens_d, w.upos_hid_w, w.upos_hid_b,
-                                                       w.upos_clf_w, w.upos_clf_b, emb, False)
-            XFa = ops.linear_split(featp, feati, arcW[0], arcW[1], w.arc_b12f, D, True, lens_d, Ld,
-                                   w.arc_b12, 3)
-            arc_logp = ops.biaffine_arc_scores(XFa, B, Ld, w.arc_Wbt, w.H, w.n_arc_scorers, w.linearization, w.distance)
+            if pack:
+                # Live words only from here to the labels (the reference's dense layers run on PackedSequence data,
+                # annotate_model.py:155-187): every row-wise op sees ONE sentence of m_live words; the arc kernel and
+                # the labels-at-heads take the packing's descriptor
+                off_d, map_d = ops.pack_descriptor(lens_d, Ld, pack[0])
+                one_d = off_d[B:]
+                encp = ops.pack_rows(enc_dep.reshape(B * Ld, -1), map_d)
+                featp, feati, _, _, _ = ops.pos_head_split(encp.view(1, pack[0], -1), one_d, w.upos_hid_w, w.upos_hid_b,
+                                                           w.upos_clf_w, w.upos_clf_b, emb, False)
+                XFa = ops.linear_split(featp, feati, arcW[0], arcW[1], w.arc_b12f, D, True, None, 0, None, 3)
+                arc_logp = ops.biaffine_arc_scores_packed(XFa, off_d, lens_d, self._arc_pad_row, B, Ld, w.arc_Wbt, w.H,
+                                                          w.n_arc_scorers, w.linearization, w.distance)
+            else:
+                featp, feati, _, _, _ = ops.pos_head_split(enc_dep.contiguous(), lens_d, w.upos_hid_w, w.upos_hid_b,
+                                                           w.upos_clf_w, w.upos_clf_b, emb, False)
+                XFa = ops.linear_split(featp, feati, arcW[0], arcW[1], w.arc_b12f, D, True, lens_d, Ld,
+                                       w.arc_b12, 3)
+                arc_logp = ops.biaffine_arc_scores(XFa, B, Ld, w.arc_Wbt, w.H, w.n_arc_scorers, w.linearization,
+                                                   w.distance)
         else:
             feat, _, _ = ops.pos_head(enc_dep.contiguous(), lens_d, w.upos_hid_w, w.upos_hid_b, w.upos_clf_w,
                                       w.upos_clf_b, w.emb_dep)
@@ -368,8 +423,11 @@ class TaskHeads:
             mst_done = torch.cuda.Event()
             mst_done.record(s_mst)
         if split:
-            XF = ops.linear_split(featp, feati, labW[0], labW[1], w.lab_b12f, D, True, lens_d, Ld,
-                                  w.lab_b12, 2)
+            if pack:
+                XF = ops.linear_split(featp, feati, labW[0], labW[1], w.lab_b12f, D, True, None, 0, None, 2)
+            else:
+                XF = ops.linear_split(featp, feati, labW[0], labW[1], w.lab_b12f, D, True, lens_d, Ld,
+                                      w.lab_b12, 2)
             x1p, x1i = ops.split_rows(XF[:, :ops.kp(w.H)])
             if tagger_later:
                 w12_done = torch.cuda.Event()
@@ -404,7 +462,12 @@ class TaskHeads:
             t.record_stream(fin)
         # labels only where annotate() reads them: at the decoded heads (ref annotate_model.py:263-266)
         with torch.cuda.stream(fin):
-            if split and fused:
+            if split and fused and pack:
+                for t in (x1i, map_d, off_d):
+                    t.record_stream(fin)
+                rels, _ = ops.label_at_heads_fused_packed(x1p, x1i, w.lab_Wbtc_s[0], w.lab_Wbtc_s[1], XF, heads, lens_d,
+                                                          map_d, off_d, w.H, w.O)
+            elif split and fused:
                 x1i.record_stream(fin)
                 rels, _ = ops.label_at_heads_fused(x1p, x1i, w.lab_Wbtc_s[0], w.lab_Wbtc_s[1], XF, heads, lens_d, w.H, w.O)
             elif split and rows4:

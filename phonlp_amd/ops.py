@@ -574,6 +574,87 @@ def label_at_heads_fused(x1p: Tensor, x1_inv: Tensor, wbtcp: Tensor, wbtc_inv: T
     return rels, best
 
 
+# ---- ragged batches with their live words packed (include/phonlp_heads.h, "packed rows")
+def pack_descriptor(sentlens: Tensor, L: int, m_live: int) -> Tuple[Tensor, Tensor]:
+    """sentlens int32 [B] (device) -> (off int32 [B+1]: sentence b's first packed row, off[B] = live rows;
+    rowmap int32 [m_live]: packed row p is word rowmap[p] = b*L + i).  m_live = sum(min(sentlens, L)), host-known."""
+    _need(sentlens, torch.int32, "sentlens")
+    B = sentlens.numel()
+    off = torch.empty(B + 1, dtype=torch.int32, device=sentlens.device)
+    rowmap = torch.empty(max(int(m_live), 1), dtype=torch.int32, device=sentlens.device)
+    check(lib().phonlp_pack_descriptor(_p(sentlens), B, int(L), _p(off), _p(rowmap), rowmap.numel(), _stream()),
+          "phonlp_pack_descriptor")
+    return off, rowmap
+
+
+def pack_rows(x: Tensor, rowmap: Tensor) -> Tensor:
+    """x fp32 [rows, W] (unit column stride) -> [len(rowmap), W]: the rows rowmap names, in order."""
+    _need(rowmap, torch.int32, "rowmap")
+    if not x.is_cuda or x.dtype != torch.float32 or x.dim() != 2 or x.stride(1) != 1:
+        raise ValueError("pack_rows: expected a 2-d fp32 ROCm tensor with unit column stride")
+    out = torch.empty((rowmap.numel(), x.shape[1]), dtype=torch.float32, device=x.device)
+    check(lib().phonlp_pack_rows(_p(x), x.stride(0), x.shape[0], _p(rowmap), rowmap.numel(), x.shape[1], _p(out), _stream()),
+          "phonlp_pack_rows")
+    return out
+
+
+def unpack_rows(x: Tensor, rowmap: Tensor, n_rows: int) -> Tensor:
+    """x [len(rowmap), W] or [len(rowmap)] (fp32 / int32) -> [n_rows, W] / [n_rows]: row p at rowmap[p], zeros elsewhere."""
+    _need(rowmap, torch.int32, "rowmap")
+    if not x.is_cuda or x.dtype not in (torch.float32, torch.int32) or not x.is_contiguous():
+        raise ValueError("unpack_rows: expected a contiguous fp32 / int32 ROCm tensor")
+    m = rowmap.numel()
+    W = x.numel() // m
+    out = torch.empty((n_rows,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    check(lib().phonlp_unpack_rows(_p(x), _p(rowmap), m, W, _p(out), int(n_rows), _stream()), "phonlp_unpack_rows")
+    return out
+
+
+def biaffine_arc_scores_packed(XF: Tensor, off: Tensor, sentlens: Tensor, pad_row: Tensor, B: int, L: int, Wbt: Tensor,
+                               H: int, n_scorers: int, use_lin: bool, use_dist: bool) -> Tensor:
+    """biaffine_arc_scores on packed rows: XF [m_live, n_scorers*2*KP]; pad_row [n_scorers*2*KP] = the first layer's
+    output for a padded (zero) hidden row.  -> arc log-probs [B,L,L]; the rows of padded dependents are NOT written."""
+    _need(XF, torch.float32, "XF")
+    _need(off, torch.int32, "off")
+    _need(sentlens, torch.int32, "sentlens")
+    _need(pad_row, torch.float32, "pad_row")
+    if pad_row.numel() != XF.shape[1]:
+        raise ValueError("biaffine_arc_scores_packed: pad_row does not match XF")
+    dev = XF.device
+    out = torch.empty((B, L, L), dtype=torch.float32, device=dev)
+    nb = lib().phonlp_biaffine_arc_scores_ws_bytes(1, XF.shape[0], H, n_scorers)
+    ws = _ws(nb, dev)
+    check(lib().phonlp_biaffine_arc_scores_packed(_p(XF), XF.shape[0], _p(off), _p(sentlens), _p(pad_row), B, L, H,
+                                                  n_scorers, int(use_lin), int(use_dist), _p(Wbt), _p(out), None, _p(ws),
+                                                  nb, _stream()), "phonlp_biaffine_arc_scores_packed")
+    return out
+
+
+def label_at_heads_fused_packed(x1p: Tensor, x1_inv: Tensor, wbtcp: Tensor, wbtc_inv: Tensor, XF: Tensor, heads: Tensor,
+                                sentlens: Tensor, rowmap: Tensor, off: Tensor, H: int, O: int) -> Tuple[Tensor, Tensor]:
+    """label_at_heads_fused on packed rows (x1p, XF: m_live rows) -> (rels int32 [B,L], winning score [B,L])."""
+    _need(x1p, torch.uint8, "x1p")
+    _need(wbtcp, torch.uint8, "wbtcp")
+    _need(XF, torch.float32, "XF")
+    _need(heads, torch.int32, "heads")
+    _need(sentlens, torch.int32, "sentlens")
+    _need(rowmap, torch.int32, "rowmap")
+    _need(off, torch.int32, "off")
+    B, L = heads.shape
+    m = rowmap.numel()
+    if x1p.shape[0] != m or XF.shape[0] != m or wbtcp.shape[0] != O * lib().phonlp_label_kpc(H) or \
+            x1p.shape[1] != wbtcp.shape[1]:
+        raise ValueError("label_at_heads_fused_packed: split images do not match rowmap, H, O")
+    rels = torch.empty((B, L), dtype=torch.int32, device=XF.device)
+    best = torch.empty((B, L), dtype=torch.float32, device=XF.device)
+    nb = lib().phonlp_label_at_heads_fused_ws_bytes(1, m, H, O)
+    ws = _ws(nb, XF.device)
+    check(lib().phonlp_label_at_heads_fused_packed(_p(x1p), _p(x1_inv), _p(wbtcp), _p(wbtc_inv), _p(XF), _p(heads),
+                                                   _p(sentlens), _p(rowmap), _p(off), m, B, L, H, O, _p(rels), _p(best),
+                                                   _p(ws), nb, _stream()), "phonlp_label_at_heads_fused_packed")
+    return rels, best
+
+
 def scatter_rows(src: Tensor, col0: int, dest_row: Tensor, dst: Tensor, status: Optional[Tensor] = None,
                  fail_count: Optional[Tensor] = None) -> None:
     """dst[dest_row[b], :n] = src[b, col0:col0+n] (device-side unsort, include/phonlp_heads.h); in place on dst."""
