@@ -34,6 +34,7 @@ struct MstArgs {
     // tree in tree0g); mode 2 = grid of B x cslots workgroups, workgroup (b, s) decodes candidates s, s + cslots, ...
     // of sentence b and leaves its best in cs_*; mst_pick_kernel then takes the first best over the slots.
     int mode, cslots;
+    int only_fb;           // mst.hip: decode only the sentences whose status is PHONLP_MST_FALLBACK (after mst_round.hip)
     uint16_t *tree0g;      // [B][L] unconstrained tree of a PENDING sentence
     double *cs_score;      // [B][cslots] best score of the slot's candidates (-inf: none finite)
     int32_t *cs_idx;       // [B][cslots] candidate number of that best (ascending ROOT-child order), -2: decode error
@@ -105,5 +106,11 @@ bool mst_fast_fits(int L);
 size_t mst_fast_bytes(int B, int L);
 void mst_fast_carve(MstArgs &a, void *base);
 int launch_mst_fast(MstArgs a, hipStream_t stream);
+
+// mst_round.hip
+bool mst_round_fits(int L);
+size_t mst_round_bytes(int B, int L);
+void mst_round_carve(MstArgs &a, void *base);
+int launch_mst_round(MstArgs a, hipStream_t stream);
 
 }  // namespace phonlp

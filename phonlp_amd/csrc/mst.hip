@@ -44,6 +44,7 @@ __global__ __launch_bounds__(1024) void mst_kernel(MstArgs a) {
     if (mode == 2) {  // candidates of a sentence the first phase left pending (block-uniform tests)
         if (a.status[b] != PHONLP_MST_PENDING || slot >= a.cand_n[b]) return;
     } else {
+        if (a.only_fb && a.status[b] != PHONLP_MST_FALLBACK) return;  // decoded by the round-based kernel already
         for (int t = tid; t < L; t += NT) hout[t] = 0;
         if (l <= 1) {  // l == 1: ROOT only -- the reference hits its broken assert (no candidate root)
             if (tid == 0) a.status[b] = l == 1 ? PHONLP_MST_NO_FINITE_TREE : PHONLP_MST_OK;
@@ -462,6 +463,7 @@ extern "C" size_t phonlp_mst_ws_bytes(int B, int L) {
         if (mst_fast_fits(L)) bytes += mst_fast_bytes(B, L);
     } else if (!mst_fits_lds(L)) {
         bytes += mst_two_phase_bytes(B, L);
+        if (mst_round_fits(L)) bytes += mst_round_bytes(B, L);
     }
     return bytes;
 }
@@ -476,12 +478,19 @@ extern "C" int phonlp_set_mst_fast_path(int on) {
     return PHONLP_OK;
 }
 extern "C" int phonlp_get_mst_fast_path(void) { return mst_fast_enabled() ? 1 : 0; }
+// long sentences: the round-based decode of mst_round.hip in front of the two-phase reference-order kernels
+static bool mst_round_path(int L) { return !mst_wave_fits(L) && !mst_fits_lds(L) && mst_round_fits(L) && mst_two_phase(); }
 extern "C" long phonlp_mst_fallback_counter_offset(int B, int L) {
-    if (B <= 0 || L <= 0 || !mst_wave_fits(L) || !mst_fast_fits(L)) return -1;
+    if (B <= 0 || L <= 0) return -1;
+    if (mst_round_path(L)) return (long)(mst_share_offset(B, L) + mst_two_phase_bytes(B, L) + CT_FB * sizeof(int32_t));
+    if (!mst_wave_fits(L) || !mst_fast_fits(L)) return -1;
     return (long)(mst_share_offset(B, L) + CT_FB * sizeof(int32_t));
 }
 extern "C" long phonlp_mst_fallback_list_offset(int B, int L) {
-    if (B <= 0 || L <= 0 || !mst_wave_fits(L) || !mst_fast_fits(L)) return -1;
+    if (B <= 0 || L <= 0) return -1;
+    if (mst_round_path(L))
+        return (long)(mst_share_offset(B, L) + mst_two_phase_bytes(B, L) + align_up((size_t)CT_COUNT * sizeof(int32_t), 256));
+    if (!mst_wave_fits(L) || !mst_fast_fits(L)) return -1;
     return (long)(mst_share_offset(B, L) + mst_share_bytes(B, L));
 }
 
@@ -556,6 +565,15 @@ extern "C" int phonlp_mst_one_root(const float *arc, const int32_t *sentlens, in
         a.cs_tree = (uint16_t *)p;
     }
     a.cslots = kCandSlots;
+    if (mst_fast_enabled() && mst_round_path(L)) {
+        // round-based decode where it provably returns the reference's tree (mst_round.hip); what it leaves with status
+        // PHONLP_MST_FALLBACK -- usually nothing -- is decoded by the reference-order kernels below
+        mst_round_carve(a, (char *)ws + mst_share_offset(B, L) + mst_two_phase_bytes(B, L));
+        const int rc = launch_mst_round(a, as_stream(stream));
+        if (rc) return rc;
+        a.only_fb = 1;
+        a.dbg = nullptr;  // diagnostic builds: the counters are the round-based kernel's
+    }
     a.mode = 1;
     hipLaunchKernelGGL(mst_kernel<false>, dim3(B), dim3(threads), lds, as_stream(stream), a);
     int rc = check_launch("mst_kernel");

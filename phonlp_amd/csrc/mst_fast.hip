@@ -778,6 +778,11 @@ __global__ void mst_fast_pick_kernel(MstArgs a) {
     if (tid == 0) a.status[b] = PHONLP_MST_OK;
 }
 
+int launch_mst_fast_pick(MstArgs a, hipStream_t stream) {  // for mst_round.hip, which follows the same slot protocol
+    hipLaunchKernelGGL(mst_fast_pick_kernel, dim3(a.B), dim3(128), 0, stream, a);
+    return check_launch("mst_fast_pick_kernel");
+}
+
 size_t mst_fast_bytes(int B, int L) {
     const size_t q = (size_t)B * kFastSlots;
     return align_up((size_t)B * sizeof(int32_t), 256) + align_up(q * sizeof(double), 256) +

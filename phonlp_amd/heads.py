@@ -194,6 +194,10 @@ class TaskHeads:
             "ones_col": env("PHONLP_ONES_COL", "1") == "1",      # unfused form: X1's ones column as a per-column bias
             # stage A fused with labels-at-heads behind the MST (T never reaches HBM): default since the round-based MST
             "label_fused": env("PHONLP_LABEL_FUSED", "1") == "1",
+            # ... up to this sentence length: beyond it the MST (matrix in global memory, csrc/mst_round.hip) takes longer
+            # than stage A, so the unfused form -- stage A beside the MST, labels-at-heads after it -- is shorter
+            # (B=64, L=512: 5.6 vs 6.2 ms)
+            "fused_max_len": int(env("PHONLP_FUSED_MAX_LEN", "128")),
             # ragged batches whose lengths the host knows: the live words packed (no arithmetic on padding); 0 = off,
             # else the largest live fraction (percent) that is still packed
             "pack_pct": int(env("PHONLP_PACK", "90")),
@@ -288,6 +292,8 @@ class TaskHeads:
         if not cfg["pack_pct"] or ops.get_gemm_engine() != 2 or w.lab_Wbt_s is None:
             return None
         if not (cfg["label_fused"] and cfg["pos_fold"] and w.arc_W12p_s is not None and cfg["tagger_fused"]):
+            return None
+        if enc_dep.shape[1] > cfg["fused_max_len"]:
             return None
 
         def host(l):
@@ -437,7 +443,7 @@ class TaskHeads:
             # Fused form (stage A after the MST with the labels-at-heads contraction in its epilogue): T (1.8 GB at the
             # headline size) is neither written nor read.  It needs the heads, so it waits for the MST -- affordable since
             # the round-based decode (csrc/mst_fast.hip); the MST runs beside the label scorer's W1/W2 layer and split.
-            fused = cfg["label_fused"]
+            fused = cfg["label_fused"] and Ld <= cfg["fused_max_len"]
             if fused:
                 T = x1p  # stage A runs after the MST, inside label_at_heads_fused (T never reaches memory)
             elif rows4:

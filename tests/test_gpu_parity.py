@@ -304,7 +304,8 @@ def test_mst_random_vs_c_oracle(dev, B, L, kind, mst_path):
         want, rc = C.mst_one_root(m)
         assert rc == 0
         assert heads[b, :m.shape[0]].tolist() == want.tolist(), f"sentence {b} l={m.shape[0]}"
-    if mst_path == "rounds" and L <= 128:
+    if mst_path == "rounds" and (L <= 128 or L >= 160):
+        # (L <= 128: csrc/mst_fast.hip; L >= 160: csrc/mst_round.hip, the matrix left in global memory)
         # float log-probabilities take the round-based kernel (a few sentences may still fall back: a sentence of 2-3
         # words whose scores tie, or sums that are not provably exact); all-ties integer matrices never do
         nfb = _run_mst.fallbacks

@@ -1,15 +1,15 @@
-"""Times the MST kernel alone on the bench's own arc scores. usage: python tools/mst_probe.py [reps]"""
+"""Times the MST kernel alone on the bench's own arc scores. usage: python tools/mst_probe.py [reps [B L]]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from phonlp_amd import HeadWeights, TaskHeads, ops, synthetic as S
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 dev = torch.device("cuda:0")
-B, L = 256, 128
+B, L = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (256, 128)
 heads = TaskHeads(HeadWeights.from_state_dict(S.make_state_dict(), dev))
 enc_dep, _ = S.make_encoder_outputs(B, L)
 lens = torch.tensor([L] * B, dtype=torch.int32, device=dev)
-arc = heads.parser(enc_dep.to(dev), lens)["arc_logp"]
+arc = heads.parser(enc_dep.to(dev), lens, want_label_argmax=False)["arc_logp"]
 ref = None
 for fast in (True, False):
     ops.set_mst_fast_path(fast)

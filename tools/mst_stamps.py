@@ -22,6 +22,8 @@ ops.mst_one_root(arc, lens); torch.cuda.synchronize()
 d = dbg.cpu().double()
 if fast:  # round-based kernel: phase 1 = rows [0, B), phase 2 = rows [B, 5B) (one per candidate slot)
     names = ["load+exact", "argmax", "detect", "label+record", "relabel", "merge+in-edge", "new-state", "expand+tail"]
+    if L > 128:  # csrc/mst_round.hip
+        names = ["scan+exact", "-", "detect", "label+record", "relabel+list", "rescan", "in-edge", "expand"]
     for ph, (lo, hi) in (("phase 1", (0, B)), ("phase 2", (B, 5 * B))):
         x = d[lo:hi]
         x = x[x[:, 11] > 0]
@@ -34,6 +36,8 @@ if fast:  # round-based kernel: phase 1 = rows [0, B), phase 2 = rows [B, 5B) (o
         for k, n in enumerate(names):
             per = "per round" if 2 <= k <= 6 else "per decode"
             den = x[:, 8].sum() if 2 <= k <= 6 else x[:, 11].sum()
+            if k == 0 and L > 128:
+                print(f"  rows rescanned per round {x[:,9].sum()/max(x[:,8].sum(),1):.1f}")
             print(f"  {n:14s} share {100*x[:,k].sum()/tot.sum():5.1f}%   {per} {x[:,k].sum()/max(den,1):8.0f} cyc")
     sys.exit(0)
 names = ["init", "argmax", "cycles", "lists", "edge+sum", "enter/leave+rec", "contract", "expand", "oneroot", "-", "-", "-", "rescan"]
