@@ -16,6 +16,7 @@ def _heads(dev, dims, pack):
     from phonlp_amd import synthetic as S
     h = TaskHeads(HeadWeights.from_state_dict(S.make_state_dict(*dims, seed=5), dev))
     h.cfg["pack_pct"] = 90 if pack else 0
+    h.cfg["fused_max_len"] = 256  # the fused (and packed) label path also for the L = 200 case (default: up to 128)
     return h
 
 
