@@ -475,6 +475,8 @@ int launch_linear_f16x3(const char *tag, const void *Xp, long pitch_x, const flo
         a.x2 = at_heads->x2; a.P = at_heads->P; a.ldx2 = at_heads->ldx2;
         a.kpc = at_heads->kpc; a.kpx = at_heads->kpx;
         a.gm = at_heads->gm;
+        static const int gm_env = getenv("PHONLP_X3_GM") ? atoi(getenv("PHONLP_X3_GM")) : 0;  // A/B: row tiles per walk group
+        if (gm_env > 0) a.gm = gm_env;
     }
     if (rows4 == 1 && (sentlens || relu || ((uintptr_t)Y & 15)))
         return fail(PHONLP_ERR_SHAPE, "linear_split: the rows-by-4 output takes no activation / padding mask");
