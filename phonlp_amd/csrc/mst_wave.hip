@@ -690,7 +690,7 @@ int launch_mst_clear(const MstArgs &a, hipStream_t stream) {
 }
 
 // a.fb_list == NULL: one workgroup per sentence.  Otherwise the sentences of the fallback list (count in ctr[CT_FB], known
-// on the device only) on a grid of at most 64 workgroups, each taking entries wg, wg + grid, ...: none, normally.
+// on the device only) on a grid of at most 16 workgroups (each needs a CU's whole LDS to itself before it can even look at the list: in the step a 64-workgroup launch with nothing to do took 20-50 us), each taking entries wg, wg + grid, ...: none, normally.
 int launch_mst_wave(MstArgs a, hipStream_t stream) {
     const WaveLayout w = wave_layout(a.L);
     int dev = 0;
@@ -703,7 +703,7 @@ int launch_mst_wave(MstArgs a, hipStream_t stream) {
             return fail(PHONLP_ERR_LAUNCH, "mst_one_root: cannot raise the dynamic LDS limit");
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    const dim3 grid(a.fb_list ? (a.B < 64 ? a.B : 64) : a.B);
+    const dim3 grid(a.fb_list ? (a.B < 16 ? a.B : 16) : a.B);
     if (a.L <= 64) hipLaunchKernelGGL(mst_wave_kernel<1>, grid, dim3(256), w.total, stream, a, w.stack_cap);
     else if (a.L <= 128) hipLaunchKernelGGL(mst_wave_kernel<2>, grid, dim3(256), w.total, stream, a, w.stack_cap);
     else hipLaunchKernelGGL(mst_wave_kernel<4>, grid, dim3(256), w.total, stream, a, w.stack_cap);

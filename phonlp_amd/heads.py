@@ -185,7 +185,7 @@ class TaskHeads:
         # what the tests run
         env = os.environ.get
         self.cfg = {
-            "mst_prio": int(env("PHONLP_MST_PRIO", "0")),        # HIP stream priority of the MST stream (-1 = high)
+            "mst_prio": int(env("PHONLP_MST_PRIO", "-1")),       # HIP stream priority of the MST stream (-1 = high: the MST is on the critical path, the GEMM beside it is not)
             "tag_prio": int(env("PHONLP_TAG_PRIO", "0")),        # ... of the tagger stream
             "tagger_fused": env("PHONLP_TAGGER_FUSED", "1") == "1",  # 0: pos_head + ner_emission instead of tagger_head
             "tagger_late": int(env("PHONLP_TAGGER_LATE", "2")),  # tagger chain start: 0 batch start, 1 arc-done, 2 behind label W1/W2 (default)
