@@ -393,6 +393,19 @@ int phonlp_dep_loss(const float *arc_logp, const float *raw, const float *T, con
                     int O, int use_lin, int use_dist, float number_of_words, float *loss, void *ws, size_t ws_bytes,
                     void *stream);
 
+/* Backward of that loss w.r.t. the OUTPUTS of the four scorers -- what autograd derives from
+ * models/jointmodel/model.py:209-236 (the linearization / distance terms are added to the unlabeled scores .detach()ed,
+ * :197,:204, so the arc cross-entropy reaches the unlabeled scorer only).  Same inputs as phonlp_dep_loss.  Outputs, every
+ * entry written: d_arc [B,L,L] = (soft-max over the sentence's own columns - one-hot(gold head)) / number_of_words on the
+ * rows 1 <= i < len, zero elsewhere; d_label [B,L,O] = (soft-max over the relations at the gold head - one-hot(gold
+ * relation)) / number_of_words on the same rows (the gradient of deprel_scores[b,i,head_i,:]; all other entries of that
+ * tensor get none); d_lin, d_dist [B,L] = the gradient of lin / dist[b,i,head_i] on EVERY row i >= 1, padded rows
+ * included (the reference masks neither term, :225-234).  No workspace. */
+int phonlp_dep_loss_grad(const float *arc_logp, const float *raw, const float *T, const float *XF,
+                         const int32_t *gold_head, const int32_t *gold_rel, const int32_t *sentlens, int B, int L, int H,
+                         int O, int use_lin, int use_dist, float number_of_words, float *d_arc, float *d_label,
+                         float *d_lin, float *d_dist, void *stream);
+
 /* POS training loss, forward value -- models/jointmodel/model.py:128-135 (pos_forward with use_soft_pos=False; crit_pos
  * :94 = CrossEntropyLoss(ignore_index=1), mean reduction), dropout the identity:
  *   loss[0] = mean over the words i < sentlens[b] with gold_upos != ignore_index of

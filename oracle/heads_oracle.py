@@ -181,7 +181,8 @@ def dep_loss(dep, sentlens, gold_head, gold_rel, number_of_words, linearization=
     masked -- padded rows contribute with whatever head the tensor holds there (0 from get_long_tensor)."""
     unl, lin, dist, lab = dep["unlabeled_raw"], dep["lin_raw"], dep["dist_raw"], dep["label_scores"]
     B, L, _ = unl.shape
-    arc = arc_epilogue(unl, lin if linearization else None, dist if distance else None)  # :188-207
+    # the two terms are added .detach()ed (:197, :204): under autograd the arc cross-entropy reaches the unlabeled scorer only
+    arc = arc_epilogue(unl, lin.detach() if linearization else None, dist.detach() if distance else None)  # :188-207
     pad = ~_row_mask(sentlens, B, L)  # word_mask: True on padding
     head = torch.as_tensor(gold_head, dtype=torch.long)
     rel = torch.as_tensor(gold_rel, dtype=torch.long)
@@ -203,6 +204,56 @@ def dep_loss(dep, sentlens, gold_head, gold_rel, number_of_words, linearization=
         t_dist = -torch.gather(kld[:, 1:], 2, head.unsqueeze(2)).sum()
     total = (t_arc + t_lab + t_lin + t_dist) / number_of_words  # :236
     return total, [t_arc, t_lab, t_lin, t_dist]
+
+
+def dep_loss_grad(dep, sentlens, gold_head, gold_rel, number_of_words, linearization=True, distance=True):
+    """The backward of ``dep_loss`` w.r.t. the four scorers' outputs, in closed form -- what autograd derives from
+    models/jointmodel/model.py:209-236 (the terms added to the unlabeled scores are .detach()ed, :197,:204, so the arc
+    cross-entropy reaches the unlabeled scorer only; crit_dep = CrossEntropyLoss(ignore_index=-1, reduction="sum"), :93):
+
+      d_unlabeled[b,i,j] = (softmax_{j' < len}(arc[b,i,:])[j] - [j == head_i]) / nw   rows 1 <= i < len, columns j < len
+      d_label[b,i,o]     = (softmax_o(label[b,i,head_i,:])[o] - [o == rel_i]) / nw    rows 1 <= i < len (at the gold head)
+      d_lin[b,i]         = (sigmoid(s) - [head_i > i]) / nw,  s = lin[b,i,head_i]     EVERY row i >= 1 (:225-230: the
+                           two-class cross-entropy of (-s/2, s/2) is not masked)
+      d_dist[b,i]        = -(|head_i - i| - pred) * sigmoid(x) / ((|head_i - i| - pred)^2 / 2 + 1) / nw,
+                           pred = 1 + softplus(x), x = dist[b,i,head_i]               EVERY row i >= 1 (:232-234)
+    Everything else is zero.  Returns a dict of B x L x L, B x L x O, B x L, B x L tensors (row 0 zero)."""
+    unl, lin, dist, lab = dep["unlabeled_raw"], dep["lin_raw"], dep["dist_raw"], dep["label_scores"]
+    B, L, _ = unl.shape
+    O = lab.shape[3]
+    nw = float(number_of_words)
+    arc = arc_epilogue(unl, lin if linearization else None, dist if distance else None)
+    live = _row_mask(sentlens, B, L)  # True on real words
+    head = torch.zeros(B, L, dtype=torch.long)
+    head[:, 1:] = torch.as_tensor(gold_head, dtype=torch.long)
+    rel = torch.zeros(B, L, dtype=torch.long)
+    rel[:, 1:] = torch.as_tensor(gold_rel, dtype=torch.long)
+    rows = live.clone()
+    rows[:, 0] = False
+    d_unl = torch.zeros(B, L, L)
+    d_lab = torch.zeros(B, L, O)
+    for b in range(B):
+        n = int(live[b].sum())
+        for i in range(1, n):
+            p = torch.softmax(arc[b, i, :n].double(), 0)
+            p[head[b, i]] -= 1.0
+            d_unl[b, i, :n] = (p / nw).float()
+            q = torch.softmax(lab[b, i, head[b, i]].double(), 0)
+            q[rel[b, i]] -= 1.0
+            d_lab[b, i] = (q / nw).float()
+    ii = torch.arange(L).view(1, L).expand(B, L)
+    d_lin = torch.zeros(B, L)
+    d_dist = torch.zeros(B, L)
+    if linearization:
+        s = torch.gather(lin, 2, head.unsqueeze(2)).squeeze(2).double()
+        d_lin = ((torch.sigmoid(s) - (head > ii).double()) / nw).float()
+        d_lin[:, 0] = 0.0
+    if distance:
+        x = torch.gather(dist, 2, head.unsqueeze(2)).squeeze(2).double()
+        diff = (head - ii).abs().double() - (1 + F.softplus(x))
+        d_dist = (-diff * torch.sigmoid(x) / (diff * diff / 2 + 1) / nw).float()
+        d_dist[:, 0] = 0.0
+    return {"d_unlabeled": d_unl, "d_label": d_lab, "d_lin": d_lin, "d_dist": d_dist}
 
 
 # --------------------------------------------------------------------------------------

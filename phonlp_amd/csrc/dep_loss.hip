@@ -131,6 +131,115 @@ __global__ __launch_bounds__(256) void dep_loss_terms_kernel(const float *arc_lo
     }
 }
 
+
+// Backward of the parser loss w.r.t. the OUTPUTS of the four scorers: what autograd derives from
+// models/jointmodel/model.py:209-236 (the terms added to the unlabeled scores are .detach()ed, :197 / :204, so the arc
+// cross-entropy reaches the unlabeled scorer only).  One block per word (b, i), the structure of dep_loss_terms_kernel:
+//   d_arc[b,i,j]   = (softmax_{j' < len}(arc[b,i,:])[j] - [j == head_i]) / nw    rows 1 <= i < len, columns j < len
+//   d_label[b,i,o] = (softmax_o(label scores at the gold head)[o] - [o == rel_i]) / nw   rows 1 <= i < len
+//   d_lin[b,i]     = (sigmoid(s) - [head_i > i]) / nw, s = lin[b,i,head_i]       EVERY row i >= 1 (unmasked, :225-230)
+//   d_dist[b,i]    = -(|head_i - i| - pred) sigmoid(x) / ((|head_i - i| - pred)^2 / 2 + 1) / nw,
+//                    pred = 1 + softplus(x), x = dist[b,i,head_i]                EVERY row i >= 1 (:232-234)
+// and zero everywhere else (every entry of the four outputs is written).  The eval log-probs differ from the masked
+// training scores by a per-row constant, which the soft-max over the sentence's own columns cancels.
+__global__ __launch_bounds__(256) void dep_loss_grad_kernel(const float *arc_logp, const float *raw, const float *T,
+                                                             const float *XF, const int32_t *gold_head,
+                                                             const int32_t *gold_rel, const int32_t *sentlens, int B,
+                                                             int L, int O, int KP, int use_lin, int use_dist, float inv_nw,
+                                                             float *d_arc, float *d_label, float *d_lin, float *d_dist) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *xs = sm, *sc = sm + KP;  // the gold head's h2 row; the O label scores
+    const int word = blockIdx.x;
+    const long M = (long)B * L;
+    const int b = word / L, i = word - b * L;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float *darow = d_arc + (long)word * L;
+    float *dlrow = d_label + (long)word * O;
+    int len = sentlens[b];
+    if (len > L) len = L;
+    const bool live = i >= 1 && i < len;
+    int h = gold_head[word];
+    if (h < 0 || h >= L) h = 0;
+    if (tid == 64) {  // the two unmasked terms
+        float g_lin = 0.f, g_dist = 0.f;
+        if (i >= 1) {
+            const long e = ((long)b * L + i) * L + h;
+            if (use_lin) {
+                const float s = raw[M * L + e];
+                g_lin = (1.f / (1.f + expf(-s)) - (h > i ? 1.f : 0.f)) * inv_nw;
+            }
+            if (use_dist) {
+                const float x = raw[2 * M * L + e];
+                const float pred = 1.f + (x > 20.f ? x : log1pf(expf(x)));  // F.softplus, threshold 20
+                const float diff = fabsf((float)(h - i)) - pred;
+                const float sg = x > 20.f ? 1.f : 1.f / (1.f + expf(-x));   // d softplus / dx (1 beyond the threshold)
+                g_dist = -diff * sg / (diff * diff / 2 + 1) * inv_nw;
+            }
+        }
+        d_lin[word] = g_lin;
+        d_dist[word] = g_dist;
+    }
+    if (!live) {  // block-uniform: ROOT row or padding
+        for (int j = tid; j < L; j += 256) darow[j] = 0.f;
+        for (int o = tid; o < O; o += 256) dlrow[o] = 0.f;
+        return;
+    }
+    const int n4 = KP >> 2;
+    const float4 *x2 = reinterpret_cast<const float4 *>(XF + ((long)b * L + h) * 2 * KP + KP);
+    float4 *xs4 = reinterpret_cast<float4 *>(xs);
+    for (int c = tid; c < n4; c += 256) xs4[c] = x2[c];
+    __syncthreads();
+    const float4 *Trow = reinterpret_cast<const float4 *>(T + (long)word * O * KP);
+    for (int o = wave; o < O; o += 12) {  // three relations per trip, as dep_loss_terms_kernel
+        float s[3] = {0.f, 0.f, 0.f};
+        for (int c = lane; c < n4; c += 64) {
+            const float4 xv = xs4[c];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int ou = o + 4 * u;
+                if (ou < O) {
+                    const float4 tv = Trow[(long)ou * n4 + c];
+                    s[u] = fmaf(tv.x, xv.x, s[u]);
+                    s[u] = fmaf(tv.y, xv.y, s[u]);
+                    s[u] = fmaf(tv.z, xv.z, s[u]);
+                    s[u] = fmaf(tv.w, xv.w, s[u]);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int ou = o + 4 * u;
+            const float v = dl_wave_sum(s[u]);
+            if (ou < O && lane == 0) sc[ou] = v;
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {  // arc: soft-max over the sentence's own columns, minus the one-hot of the gold head
+        const float *row = arc_logp + ((long)b * L + i) * L;
+        float m = -INFINITY;
+        for (int j = lane; j < len; j += 64) m = fmaxf(m, row[j]);
+        m = dl_wave_max(m);
+        float s = 0.f;
+        for (int j = lane; j < len; j += 64) s += expf(row[j] - m);
+        s = dl_wave_sum(s);
+        const float is = 1.f / s;
+        for (int j = lane; j < L; j += 64)
+            darow[j] = j < len ? (expf(row[j] - m) * is - (j == h ? 1.f : 0.f)) * inv_nw : 0.f;
+    } else if (wave == 1) {  // label: soft-max over the relations at the gold head, minus the one-hot of the gold relation
+        const int r = gold_rel[word];
+        const bool counted = r >= 0 && r < O;  // -1 = ignore_index
+        float m = -INFINITY;
+        for (int o = lane; o < O; o += 64) m = fmaxf(m, sc[o]);
+        m = dl_wave_max(m);
+        float s = 0.f;
+        for (int o = lane; o < O; o += 64) s += expf(sc[o] - m);
+        s = dl_wave_sum(s);
+        const float is = 1.f / s;
+        for (int o = lane; o < O; o += 64)
+            dlrow[o] = counted ? (expf(sc[o] - m) * is - (o == r ? 1.f : 0.f)) * inv_nw : 0.f;
+    }
+}
+
 // loss[0..3] = the four sums, loss[4] = their total / number_of_words.  One block of 1024 threads; double accumulators
 // in a fixed order (thread t takes entries t, t+1024, ..., eight loads in flight; then a tree over the block), so the
 // value does not depend on timing.
@@ -275,6 +384,26 @@ extern "C" int phonlp_dep_loss(const float *arc_logp, const float *raw, const fl
     ProfScope ps("dep_loss_sum", st);
     hipLaunchKernelGGL(dep_loss_sum_kernel, dim3(1), dim3(1024), 0, st, terms, (long)B * L, number_of_words, loss);
     return check_launch("dep_loss_sum_kernel");
+}
+
+extern "C" int phonlp_dep_loss_grad(const float *arc_logp, const float *raw, const float *T, const float *XF,
+                                    const int32_t *gold_head, const int32_t *gold_rel, const int32_t *sentlens, int B,
+                                    int L, int H, int O, int use_lin, int use_dist, float number_of_words, float *d_arc,
+                                    float *d_label, float *d_lin, float *d_dist, void *stream) {
+    if (!arc_logp || !T || !XF || !gold_head || !gold_rel || !sentlens || !d_arc || !d_label || !d_lin || !d_dist ||
+        B <= 0 || L <= 0 || H <= 0 || O <= 0)
+        return fail(PHONLP_ERR_SHAPE, "dep_loss_grad: bad argument");
+    if ((use_lin || use_dist) && !raw) return fail(PHONLP_ERR_SHAPE, "dep_loss_grad: raw scorer outputs needed");
+    if (!(number_of_words > 0.f)) return fail(PHONLP_ERR_SHAPE, "dep_loss_grad: number_of_words must be positive");
+    if (((uintptr_t)T & 15) || ((uintptr_t)XF & 15)) return fail(PHONLP_ERR_SHAPE, "dep_loss_grad: T, XF must be 16-byte aligned");
+    const int KP = kp_of(H);
+    const size_t lds = (size_t)(KP + O) * sizeof(float);
+    if (lds > 64 * 1024) return fail(PHONLP_ERR_UNSUPPORTED, "dep_loss_grad: H + O too large for one LDS row");
+    hipStream_t st = as_stream(stream);
+    ProfScope ps("dep_loss_grad", st);
+    hipLaunchKernelGGL(dep_loss_grad_kernel, dim3(B * L), dim3(256), lds, st, arc_logp, raw, T, XF, gold_head, gold_rel,
+                       sentlens, B, L, O, KP, use_lin, use_dist, 1.f / number_of_words, d_arc, d_label, d_lin, d_dist);
+    return check_launch("dep_loss_grad_kernel");
 }
 
 extern "C" size_t phonlp_pos_loss_ws_bytes(int B, int L) {

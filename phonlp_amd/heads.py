@@ -260,6 +260,29 @@ class TaskHeads:
         return ops.dep_loss(dep["arc_logp"], dep.get("raw"), T, XF, with_root(gold_head), with_root(gold_rel), lens,
                             w.H, w.O, w.linearization and w.n_arc_scorers > 1, w.distance and w.n_arc_scorers > 1, nw)
 
+    # ---- backward of that loss w.r.t. the four scorers' outputs (autograd of ref jointmodel/model.py:209-236)
+    def parser_loss_grad(self, enc: torch.Tensor, sentlens, gold_head, gold_rel, number_of_words=None):
+        """-> dict of device tensors: d_unlabeled [B,L,L], d_label [B,L,O] (the gradient of deprel_scores[b,i,head_i,:]),
+        d_lin, d_dist [B,L] (of lin / dist[b,i,head_i]) -- everything the reference's loss.backward() sends into the
+        scorers with the model in .eval(); all other entries of their outputs get no gradient."""
+        w = self.w
+        dep = self.parser(enc, sentlens, want_raw=w.n_arc_scorers > 1, want_label_argmax=False)
+        lens = dep["sentlens"]
+        L = enc.shape[1]
+
+        def with_root(t):
+            t = torch.as_tensor(t).to(device=enc.device, dtype=torch.int32)
+            if t.shape[1] == L - 1:
+                t = torch.nn.functional.pad(t, (1, 0))
+            return t.contiguous()
+
+        XF, T = ops.label_project(dep["hidden_out"], w.lab_W12, w.lab_b12, w.lab_Wbt, w.H, w.O)
+        nw = float(lens.sum().item()) if number_of_words is None else float(number_of_words)
+        d_arc, d_label, d_lin, d_dist = ops.dep_loss_grad(
+            dep["arc_logp"], dep.get("raw"), T, XF, with_root(gold_head), with_root(gold_rel), lens, w.H, w.O,
+            w.linearization and w.n_arc_scorers > 1, w.distance and w.n_arc_scorers > 1, nw)
+        return {"d_unlabeled": d_arc, "d_label": d_label, "d_lin": d_lin, "d_dist": d_dist}
+
     # ---- training model's pos_forward(use_soft_pos=False) after the gather, loss value only (ref jointmodel/model.py:128-135)
     def pos_loss(self, enc: torch.Tensor, sentlens, gold_upos, ignore_index=1) -> torch.Tensor:
         """-> fp32 [3] on the device: mean cross-entropy (what the reference returns as `loss`), sum, words counted."""

@@ -328,6 +328,38 @@ def dep_loss(arc_logp: Tensor, raw: Optional[Tensor], T: Tensor, XF: Tensor, gol
     return loss
 
 
+def dep_loss_grad(arc_logp: Tensor, raw: Optional[Tensor], T: Tensor, XF: Tensor, gold_head: Tensor, gold_rel: Tensor,
+                  sentlens: Tensor, H: int, O: int, use_lin: bool, use_dist: bool,
+                  number_of_words: float) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+    """Backward of dep_loss w.r.t. the four scorers' outputs (autograd of ref models/jointmodel/model.py:209-236):
+    -> (d_arc [B,L,L], d_label [B,L,O] at the gold head, d_lin [B,L], d_dist [B,L] at the gold head); include/phonlp_heads.h."""
+    _need(arc_logp, torch.float32, "arc_logp")
+    _need(T, torch.float32, "T")
+    _need(XF, torch.float32, "XF")
+    _need(gold_head, torch.int32, "gold_head")
+    _need(gold_rel, torch.int32, "gold_rel")
+    _need(sentlens, torch.int32, "sentlens")
+    if raw is not None:
+        _need(raw, torch.float32, "raw")
+    B, L = gold_head.shape
+    if tuple(arc_logp.shape) != (B, L, L) or tuple(gold_rel.shape) != (B, L) or sentlens.numel() != B:
+        raise ValueError("dep_loss_grad: arc_logp [B,L,L], gold_head/gold_rel [B,L], sentlens [B] expected")
+    if raw is not None and tuple(raw.shape) != (3, B, L, L):
+        raise ValueError("dep_loss_grad: raw must be [3,B,L,L]")
+    KP = kp(H)
+    if T.numel() != B * L * O * KP or XF.numel() != B * L * 2 * KP:
+        raise ValueError("dep_loss_grad: T [B*L, O*KP] and XF [B*L, 2*KP] of label_project expected")
+    dev = arc_logp.device
+    d_arc = torch.empty((B, L, L), dtype=torch.float32, device=dev)
+    d_label = torch.empty((B, L, O), dtype=torch.float32, device=dev)
+    d_lin = torch.empty((B, L), dtype=torch.float32, device=dev)
+    d_dist = torch.empty((B, L), dtype=torch.float32, device=dev)
+    check(lib().phonlp_dep_loss_grad(_p(arc_logp), _p(raw), _p(T), _p(XF), _p(gold_head), _p(gold_rel), _p(sentlens), B,
+                                     L, H, O, int(use_lin), int(use_dist), float(number_of_words), _p(d_arc), _p(d_label),
+                                     _p(d_lin), _p(d_dist), _stream()), "phonlp_dep_loss_grad")
+    return d_arc, d_label, d_lin, d_dist
+
+
 @dep_loss.register_fake
 def _(arc_logp, raw, T, XF, gold_head, gold_rel, sentlens, H, O, use_lin, use_dist, number_of_words):
     return arc_logp.new_empty((5,))

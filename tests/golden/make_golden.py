@@ -516,6 +516,94 @@ def gen_dep_loss():
     save("dep_loss_small.npz", **arrs)
 
 
+
+# ---------------------------------------------------------------------------- F9b backward of the parser loss
+def gen_dep_loss_grad():
+    """The backward that autograd derives from models/jointmodel/model.py:209-236 (eval=False branch of dep_forward,
+    model in .eval()): gradients of the loss w.r.t. the OUTPUTS of the four scorers (unlabeled / deprel / linearization /
+    distance), read off the reference's own graph after loss.backward().  The deprel / linearization / distance
+    gradients are non-zero only at the gold head (checked here), so only those entries are stored."""
+    import tempfile
+    amodel = build_joint_model(seed=909)
+    from phonlp.models.jointmodel.trainer import JointTrainer
+    with tempfile.TemporaryDirectory() as td:
+        amodel.phobert.save_pretrained(td)
+        args = dict(amodel.args, pretrained_lm=td)
+        trainer = JointTrainer(args=args, vocab=amodel.vocab, config_phobert=amodel.phobert.config, use_cuda=False)
+    missing, unexpected = trainer.model.load_state_dict(amodel.state_dict(), strict=False)
+    assert not unexpected and all(m.startswith("drop_replacement") for m in missing), (missing, unexpected)
+    model = trainer.model.eval()
+    with open(os.path.join(REF, "sample_data", "input.txt")) as f:
+        lines = [ln.strip() for ln in f if ln.strip()]
+    arrs = {f"p_{k}": v for k, v in head_state(amodel).items()}
+    captured = []
+    orig = model.phobert.forward
+    model.phobert.forward = lambda *a, **kw: (captured.append(orig(*a, **kw)), captured[-1])[1]
+    grads = {}
+
+    def keep(name):
+        def hook(_mod, _inp, out):
+            # the gradient that flows back INTO the scorer.  dep_forward edits the scorer's output in place through a
+            # view, which detaches tensor hooks from it; so the caller gets a copy to edit and the hook sits on the
+            # untouched original (a clone is the identity for values and gradients)
+            out.register_hook(lambda gr: grads.__setitem__(name, gr.detach().clone()))
+            return out.clone()
+        return hook
+
+    for name in ("unlabeled", "deprel", "linearization", "distance"):
+        getattr(model, name).register_forward_hook(keep(name))
+    g = torch.Generator().manual_seed(12)
+    cases = [lines[70:80] + ["x", "y z w"], lines[5:8], ["p q r"]]
+    for c, text in enumerate(cases):
+        sents = [ln.split(" ") for ln in text]
+        data_p = amodel.chunk_batches(amodel.process_data_parser(batch_text=sents), len(sents))
+        tok, fsw, wmask, _, _, lens = amodel.get_batch(0, data_p)
+        B, L = len(lens), max(lens)
+        head = torch.zeros(B, L - 1, dtype=torch.long)
+        rel = torch.zeros(B, L - 1, dtype=torch.long)
+        for b, ln in enumerate(lens):
+            for i in range(1, ln):  # any head but the word itself, as in a treebank (zeros stay on padding)
+                h = int(torch.randint(0, ln - 1, (1,), generator=g))
+                head[b, i - 1] = h if h < i else h + 1
+                rel[b, i - 1] = int(torch.randint(4, len(amodel.vocab["deprel"]), (1,), generator=g))
+        nwords = int(sum(lens))
+        model.zero_grad()
+        grads.clear()
+        loss, _ = model.dep_forward(tok, fsw, wmask, nwords, lens, head, rel, eval=False)
+        loss.backward()
+        enc = captured[-1][2][-1].detach()
+        O = len(amodel.vocab["deprel"])
+        d_unl = grads["unlabeled"].squeeze(3)      # B x L x L
+        d_dep = grads["deprel"]                    # B x L x L x O
+        d_lin = grads["linearization"].squeeze(3)  # B x L x L
+        d_dst = grads["distance"].squeeze(3)
+        hd = head.unsqueeze(2)
+        at = lambda t: torch.gather(t[:, 1:], 2, hd).squeeze(2)  # B x (L-1): the entry at the gold head
+        d_dep_h = torch.gather(d_dep[:, 1:], 2, head.view(B, L - 1, 1, 1).expand(-1, -1, -1, O)).squeeze(2)  # B x (L-1) x O
+        # everything else is exactly zero in the reference's gradient
+        z = d_dep.clone()
+        z[:, 1:].scatter_(2, head.view(B, L - 1, 1, 1).expand(-1, -1, -1, O), 0.0)
+        assert not z.any()
+        for t in (d_lin, d_dst):
+            z = t.clone()
+            z[:, 1:].scatter_(2, hd, 0.0)
+            assert not z.any()
+        assert not d_unl[:, 0].any()
+        arrs[f"c{c}_enc"] = torch.stack([enc[i].index_select(0, fsw[i]) for i in range(B)]).numpy()
+        arrs[f"c{c}_lens"] = np.asarray(lens, dtype=np.int64)
+        arrs[f"c{c}_head"], arrs[f"c{c}_rel"] = head.numpy(), rel.numpy()
+        arrs[f"c{c}_nwords"] = np.int64(nwords)
+        arrs[f"c{c}_loss"] = np.float32(loss.item())
+        arrs[f"c{c}_d_unlabeled"] = d_unl.numpy()
+        arrs[f"c{c}_d_label"] = d_dep_h.numpy()
+        arrs[f"c{c}_d_lin"] = at(d_lin).numpy()
+        arrs[f"c{c}_d_dist"] = at(d_dst).numpy()
+        print(f"dep loss grad case {c}: B={B} L={L} loss={loss.item():.6f} |d_unl|={d_unl.abs().sum():.4f} "
+              f"|d_label|={d_dep_h.abs().sum():.4f} |d_lin|={at(d_lin).abs().sum():.4f} |d_dist|={at(d_dst).abs().sum():.4f}")
+    arrs["n_cases"] = np.int64(len(cases))
+    save("dep_loss_grad_small.npz", **arrs)
+
+
 # ---------------------------------------------------------------------------- F10 BASELINE config 1 at full head sizes
 def gen_config1():
     """BASELINE config 1: the reference's annotate() (annotate_model.py:218-339) over all 100 sentences of
@@ -616,6 +704,9 @@ if __name__ == "__main__":
     if "--only-dep-loss" in sys.argv:
         gen_dep_loss()
         sys.exit(0)
+    if "--only-dep-loss-grad" in sys.argv:
+        gen_dep_loss_grad()
+        sys.exit(0)
     torch.set_num_threads(4)
     gen_biaffine()
     gen_viterbi()
@@ -626,4 +717,5 @@ if __name__ == "__main__":
     gen_ner_entities()
     gen_trainer()
     gen_dep_loss()
+    gen_dep_loss_grad()
     gen_config1()

@@ -162,3 +162,44 @@ def test_pos_cross_entropy_module_backward(dev, N, U):
     (3.0 * got).backward()
     assert _rel(got.detach().cpu(), want.detach()) <= 1e-5
     torch.testing.assert_close(xg.grad, xr.grad, rtol=1e-4, atol=1e-7)
+
+
+# ------------------------------------------------------------------------------------------ backward w.r.t. the scores
+def test_dep_loss_grad_reference_fixture(dev, engine, golden):
+    """phonlp_dep_loss_grad against the gradients the reference's own graph sent into its four scorers
+    (dep_loss_grad_small.npz: autograd of jointmodel/model.py:209-236 under loss.backward(), model in .eval()).
+    Tolerance 1e-4 relative + 1e-6 absolute (gradients are soft-max probabilities / number_of_words)."""
+    from phonlp_amd import HeadWeights, TaskHeads
+    z = golden("dep_loss_grad_small.npz")
+    heads = TaskHeads(HeadWeights.from_state_dict(_params(z), dev))
+    for c in range(int(z["n_cases"])):
+        lens = z[f"c{c}_lens"].tolist()
+        g = heads.parser_loss_grad(torch.from_numpy(z[f"c{c}_enc"]).to(dev), lens, torch.from_numpy(z[f"c{c}_head"]),
+                                   torch.from_numpy(z[f"c{c}_rel"]), int(z[f"c{c}_nwords"]))
+        tt = lambda k: torch.from_numpy(z[f"c{c}_{k}"])
+        torch.testing.assert_close(g["d_unlabeled"].cpu(), tt("d_unlabeled"), rtol=1e-4, atol=1e-6)
+        torch.testing.assert_close(g["d_label"].cpu()[:, 1:], tt("d_label"), rtol=1e-4, atol=1e-6)
+        torch.testing.assert_close(g["d_lin"].cpu()[:, 1:], tt("d_lin"), rtol=1e-4, atol=1e-6)
+        torch.testing.assert_close(g["d_dist"].cpu()[:, 1:], tt("d_dist"), rtol=1e-4, atol=1e-6)
+        assert not g["d_label"][:, 0].any() and not g["d_lin"][:, 0].any() and not g["d_dist"][:, 0].any()
+
+
+@pytest.mark.parametrize("B,L,ragged,lin,dist", [(8, 64, True, True, True), (6, 128, False, True, True),
+                                                 (5, 40, True, False, True), (4, 33, True, False, False),
+                                                 (2, 200, True, True, True)])
+def test_dep_loss_grad_vs_oracle(dev, engine, B, L, ragged, lin, dist):
+    """The same at the real head sizes against the oracle's closed form (itself pinned to the reference's autograd by
+    tests/test_oracle_golden.py::test_dep_loss_gradients)."""
+    from phonlp_amd import HeadWeights, TaskHeads
+    from phonlp_amd import synthetic as S
+    sd = S.make_state_dict()
+    enc_dep, _ = S.make_encoder_outputs(B, L)
+    lens1 = S.make_sentlens(B, L, ragged)
+    head, rel = _gold_trees(lens1, L, 33, seed=B * L)
+    nw = sum(lens1)
+    heads = TaskHeads(HeadWeights.from_state_dict(sd, dev, linearization=lin, distance=dist))
+    g = heads.parser_loss_grad(enc_dep.to(dev), lens1, head, rel, nw)
+    dep = O.dep_heads(enc_dep, lens1, sd, linearization=lin, distance=dist)
+    want = O.dep_loss_grad(dep, lens1, head[:, 1:], rel[:, 1:], nw, linearization=lin, distance=dist)
+    for k in ("d_unlabeled", "d_label", "d_lin", "d_dist"):
+        torch.testing.assert_close(g[k].cpu(), want[k], rtol=2e-4, atol=1e-6, msg=lambda m: f"{k}: {m}")

@@ -134,6 +134,40 @@ def test_dep_loss(golden):
         assert abs(got - float(z[f"c{c}_pos_loss"])) <= 2e-5 * abs(float(z[f"c{c}_pos_loss"]))
 
 
+def test_dep_loss_gradients(golden):
+    """The closed-form backward of the parser loss (oracle.dep_loss_grad) against the gradients the reference's own
+    graph produced at the outputs of its four scorers (dep_loss_grad_small.npz), and against autograd through the
+    oracle's dep_loss."""
+    z = golden("dep_loss_grad_small.npz")
+    p = _params(z)
+    for c in range(int(z["n_cases"])):
+        lens = z[f"c{c}_lens"].tolist()
+        nw = int(z[f"c{c}_nwords"])
+        dep = O.dep_heads(torch.from_numpy(z[f"c{c}_enc"]), lens, p)
+        total, _ = O.dep_loss(dep, lens, z[f"c{c}_head"], z[f"c{c}_rel"], nw)
+        assert abs(float(total) - float(z[f"c{c}_loss"])) <= 2e-5 * abs(float(z[f"c{c}_loss"]))
+        g = O.dep_loss_grad(dep, lens, z[f"c{c}_head"], z[f"c{c}_rel"], nw)
+        tt = lambda k: torch.from_numpy(z[f"c{c}_{k}"])
+        torch.testing.assert_close(g["d_unlabeled"], tt("d_unlabeled"), rtol=1e-4, atol=1e-7)
+        torch.testing.assert_close(g["d_label"][:, 1:], tt("d_label"), rtol=1e-4, atol=1e-7)
+        torch.testing.assert_close(g["d_lin"][:, 1:], tt("d_lin"), rtol=1e-4, atol=1e-7)
+        torch.testing.assert_close(g["d_dist"][:, 1:], tt("d_dist"), rtol=1e-4, atol=1e-7)
+        assert not g["d_label"][:, 0].any() and not g["d_lin"][:, 0].any() and not g["d_dist"][:, 0].any()
+        # autograd through the oracle's own loss says the same
+        leaves = {k: dep[k].clone().requires_grad_(True) for k in ("unlabeled_raw", "lin_raw", "dist_raw", "label_scores")}
+        t2, _ = O.dep_loss(dict(dep, **leaves), lens, z[f"c{c}_head"], z[f"c{c}_rel"], nw)
+        t2.backward()
+        torch.testing.assert_close(leaves["unlabeled_raw"].grad, g["d_unlabeled"], rtol=1e-4, atol=1e-7)
+        head = torch.zeros(len(lens), max(lens), dtype=torch.long)
+        head[:, 1:] = tt("head")
+        at = lambda t: torch.gather(t, 2, head.unsqueeze(2)).squeeze(2)
+        torch.testing.assert_close(at(leaves["lin_raw"].grad)[:, 1:], g["d_lin"][:, 1:], rtol=1e-4, atol=1e-7)
+        torch.testing.assert_close(at(leaves["dist_raw"].grad)[:, 1:], g["d_dist"][:, 1:], rtol=1e-4, atol=1e-7)
+        B, L, _, O_ = dep["label_scores"].shape
+        lab_h = torch.gather(leaves["label_scores"].grad, 2, head.view(B, L, 1, 1).expand(-1, -1, -1, O_)).squeeze(2)
+        torch.testing.assert_close(lab_h[:, 1:], g["d_label"][:, 1:], rtol=1e-4, atol=1e-7)
+
+
 def test_crf_nll_gradients(golden):
     """Autograd through the oracle's crf_nll against the gradients the reference's own CRFLoss produced."""
     z = golden("crf.npz")

@@ -39,6 +39,8 @@ def timed(fn, n=20):
 t_dep = timed(lambda: ops.dep_loss(dep["arc_logp"], dep["raw"], T, XF, head, rel, dep["sentlens"], w.H, w.O, True, True, float(B * L)))
 t_pos = timed(lambda: ops.pos_loss(tag["upos_logits"], gold, tag["sentlens"], 1))
 nbytes = T.numel() * 4 + dep["arc_logp"].numel() * 4
+t_dlg = timed(lambda: ops.dep_loss_grad(dep["arc_logp"], dep["raw"], T, XF, head, rel, dep["sentlens"], w.H, w.O, True, True, float(B * L)))
+print(f"dep_loss_grad {t_dlg:.3f} ms ({(nbytes + 4.0 * B * L * L) / t_dlg / 1e6:.0f} GB/s over T + arc_logp + d_arc)")
 print(f"dep_loss {t_dep:.3f} ms ({nbytes / t_dep / 1e6:.0f} GB/s over T + arc_logp = {nbytes / 1e9:.2f} GB), pos_loss {t_pos:.3f} ms")
 from phonlp_amd.profile import KernelTimer
 ner_gold = torch.randint(0, w.trans.shape[0], (B, L - 1), generator=g).to(dev, torch.int32)
