@@ -529,9 +529,10 @@ extern "C" int phonlp_mst_one_root(const float *arc, const int32_t *sentlens, in
     if (mst_wave_fits(L) && !blocksync) {
         const size_t off = mst_share_offset(B, L);
         mst_share_carve(a, (char *)ws + off);
-        int rc = launch_mst_clear(a, as_stream(stream));
+        const bool fast = mst_fast_enabled() && mst_fast_fits(L);
+        int rc = fast ? 0 : launch_mst_clear(a, as_stream(stream));  // the round-based path clears the region itself (phase 2)
         if (rc) return rc;
-        if (mst_fast_enabled() && mst_fast_fits(L)) {
+        if (fast) {
             // round-based decode where it provably returns the reference's tree; the rest lands on the fallback list,
             // which the reference-order kernel below then decodes (usually nothing)
             mst_fast_carve(a, (char *)ws + off + mst_share_bytes(B, L));

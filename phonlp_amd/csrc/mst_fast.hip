@@ -159,6 +159,15 @@ __global__ __launch_bounds__(256) void mst_fast_kernel(MstArgs a, int pitch, int
     int32_t *hout = a.heads + (long)b * L;
     int ncand = 1;
     if (mode == 2) {
+        // The shared region of the reference-order kernel (its counters, candidate queue and per-sentence counts) is
+        // cleared here, by slot 0 of every sentence, instead of by a launch of its own in front of phase 1: nothing
+        // touches the region before the pick kernel, and that launch sat on the critical path of the step, waiting
+        // ~80 us for a SIMD slot behind the GEMM of the main stream.
+        if (slot == 0) {
+            for (int t = tid; t < L; t += 256) a.tasks[(long)b * L + t] = 0;
+            if (tid == 0) a.cand_left[b] = 0;
+            if (b == 0 && tid < CT_COUNT) a.ctr[tid] = 0;
+        }
         if (a.status[b] != PHONLP_MST_PENDING) return;
         ncand = a.cand_n[b];
         if (slot >= ncand) return;
@@ -237,7 +246,7 @@ __global__ __launch_bounds__(256) void mst_fast_kernel(MstArgs a, int pitch, int
         if (!exact) {  // block-uniform
             if (tid == 0) {
                 a.status[b] = PHONLP_MST_FALLBACK;
-                a.fb_list[atomicAdd(&a.ctr[CT_FB], 1)] = b | (1 << 24);  // bits 24+: why (diagnostics): 1 = (G)
+                a.cand_n[b] = 1;  // why (diagnostics; the pick kernel lists the sentence): 1 = (G)
             }
             return;
         }
@@ -741,7 +750,7 @@ __global__ __launch_bounds__(256) void mst_fast_kernel(MstArgs a, int pitch, int
         if (mode == 1) {
             if (failed) {
                 a.status[b] = PHONLP_MST_FALLBACK;
-                a.fb_list[atomicAdd(&a.ctr[CT_FB], 1)] = b | (2 << 24);  // 2 = (U) or the round limit, unconstrained decode
+                a.cand_n[b] = 2;  // 2 = (U) or the round limit, unconstrained decode
             }
         } else {
             const long qx = (long)b * CS + slot;
@@ -755,6 +764,10 @@ __global__ __launch_bounds__(256) void mst_fast_kernel(MstArgs a, int pitch, int
 // reference's strict '>' in candidate order, :159); a slot that could not decide sends the sentence to the fallback.
 __global__ void mst_fast_pick_kernel(MstArgs a) {
     const int b = blockIdx.x, tid = threadIdx.x, L = a.L, R = a.cslots;
+    if (a.status[b] == PHONLP_MST_FALLBACK) {  // phase 1 gave the sentence up: list it (reason in cand_n)
+        if (tid == 0) a.fb_list[atomicAdd(&a.ctr[CT_FB], 1)] = b | (a.cand_n[b] << 24);
+        return;
+    }
     if (a.status[b] != PHONLP_MST_PENDING) return;
     int l = a.sentlens[b];
     if (l > L) l = L;
@@ -798,7 +811,8 @@ void mst_fast_carve(MstArgs &a, void *base) {
     a.cslots = kFastSlots;
 }
 
-// phases 1-3; the caller has cleared a.ctr and runs the reference-order kernel over the fallback list afterwards
+// phases 1-3 (phase 2 clears the shared region, a.ctr included; the pick kernel then builds the fallback list); the
+// caller runs the reference-order kernel over that list afterwards
 int launch_mst_fast(MstArgs a, hipStream_t stream) {
     const FastLayout f = fast_layout(a.L);
     int dev = 0;

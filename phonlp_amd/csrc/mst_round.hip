@@ -164,6 +164,7 @@ __global__ __launch_bounds__(1024) void mst_round_kernel(MstArgs a) {
     int32_t *hout = a.heads + (long)b * L;
     int ncand = 1;
     if (mode == 2) {
+        if (blockIdx.x == 0 && tid < CT_COUNT) a.ctr[tid] = 0;  // the fallback counter: first used by the pick kernel
         if (a.status[b] != PHONLP_MST_PENDING) return;
         ncand = a.cand_n[b];
         if (slot >= ncand) return;
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(1024) void mst_round_kernel(MstArgs a) {
             if (!exact) {  // block-uniform
                 if (tid == 0) {
                     a.status[b] = PHONLP_MST_FALLBACK;
-                    a.fb_list[atomicAdd(&a.ctr[CT_FB], 1)] = b | (1 << 24);  // bits 24+: why (diagnostics): 1 = (G)
+                    a.cand_n[b] = 1;  // why (diagnostics; the pick kernel lists the sentence): 1 = (G)
                 }
                 return;
             }
@@ -402,7 +403,7 @@ __global__ __launch_bounds__(1024) void mst_round_kernel(MstArgs a) {
         if (mode == 1) {
             if (failed) {
                 a.status[b] = PHONLP_MST_FALLBACK;
-                a.fb_list[atomicAdd(&a.ctr[CT_FB], 1)] = b | (2 << 24);  // 2 = (U), unconstrained decode
+                a.cand_n[b] = 2;  // 2 = (U), unconstrained decode
             }
         } else {
             const long qx = (long)b * CS + slot;
@@ -438,8 +439,6 @@ int launch_mst_round(MstArgs a, hipStream_t stream) {
                 return fail(PHONLP_ERR_LAUNCH, "mst_one_root: cannot raise the dynamic LDS limit");
         attr_once.mark(attr_dev);
     }
-    if (hipMemsetAsync(a.ctr, 0, CT_COUNT * sizeof(int32_t), stream) != hipSuccess)
-        return fail(PHONLP_ERR_LAUNCH, "mst_one_root: hipMemsetAsync failed");
     static const int nt_env = getenv("PHONLP_MST_ROUND_NT") ? atoi(getenv("PHONLP_MST_ROUND_NT")) : 0;  // A/B switch
     int threads = a.L <= 256 ? 512 : 1024;  // one thread per word; the waves beyond that speed up the row rescans
     if (nt_env >= a.L && nt_env <= 1024 && (nt_env & 63) == 0) threads = nt_env;

@@ -185,7 +185,7 @@ class TaskHeads:
         # what the tests run
         env = os.environ.get
         self.cfg = {
-            "mst_prio": int(env("PHONLP_MST_PRIO", "-1")),       # HIP stream priority of the MST stream (-1 = high: the MST is on the critical path, the GEMM beside it is not)
+            "mst_prio": int(env("PHONLP_MST_PRIO", "0")),        # HIP stream priority of the MST stream (-1 = high; see DESIGN.md section 9 before using it)
             "tag_prio": int(env("PHONLP_TAG_PRIO", "0")),        # ... of the tagger stream
             "tagger_fused": env("PHONLP_TAGGER_FUSED", "1") == "1",  # 0: pos_head + ner_emission instead of tagger_head
             "tagger_late": int(env("PHONLP_TAGGER_LATE", "2")),  # tagger chain start: 0 batch start, 1 arc-done, 2 behind label W1/W2 (default)
@@ -486,7 +486,6 @@ class TaskHeads:
             for t in (XF, T, lens_d, lens_t):
                 t.record_stream(fin)
         fin.wait_event(mst_done)
-        fin.wait_event(tag_done)
         for t in (heads, status, ner, tag["pos_pred"]):
             t.record_stream(fin)
         # labels only where annotate() reads them: at the decoded heads (ref annotate_model.py:263-266)
@@ -503,6 +502,8 @@ class TaskHeads:
                 rels, _ = ops.label_at_heads_rows4(T, XF, heads, lens_d, w.H, w.O)
             else:
                 rels, _ = ops.label_at_heads(T, XF, heads, lens_d, w.H, w.O)
+            # the tagger chain joins here, behind the label kernels (they do not read its results)
+            fin.wait_event(tag_done)
             done = torch.cuda.Event()
             done.record(fin)
         return {"pos": tag["pos_pred"], "ner": ner, "heads": heads, "rels": rels, "mst_status": status,
