@@ -815,14 +815,13 @@ void mst_fast_carve(MstArgs &a, void *base) {
 // caller runs the reference-order kernel over that list afterwards
 int launch_mst_fast(MstArgs a, hipStream_t stream) {
     const FastLayout f = fast_layout(a.L);
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    static bool attr_set[64] = {false};
-    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+    static PerDeviceOnce attr_once;
+    int dev;
+    if (attr_once.pending(&dev)) {
         if (hipFuncSetAttribute((const void *)mst_fast_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
             hipFuncSetAttribute((const void *)mst_fast_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return fail(PHONLP_ERR_LAUNCH, "mst_one_root: cannot raise the dynamic LDS limit");
-        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+        attr_once.mark(dev);
     }
     for (int mode = 1; mode <= 2; ++mode) {
         a.mode = mode;

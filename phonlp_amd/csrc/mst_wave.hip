@@ -693,15 +693,14 @@ int launch_mst_clear(const MstArgs &a, hipStream_t stream) {
 // on the device only) on a grid of at most 16 workgroups (each needs a CU's whole LDS to itself before it can even look at the list: in the step a 64-workgroup launch with nothing to do took 20-50 us), each taking entries wg, wg + grid, ...: none, normally.
 int launch_mst_wave(MstArgs a, hipStream_t stream) {
     const WaveLayout w = wave_layout(a.L);
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    static bool attr_set[64] = {false};  // the attribute is per device
-    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+    static PerDeviceOnce attr_once;  // the attribute is per device
+    int dev;
+    if (attr_once.pending(&dev)) {
         if (hipFuncSetAttribute((const void *)mst_wave_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
             hipFuncSetAttribute((const void *)mst_wave_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
             hipFuncSetAttribute((const void *)mst_wave_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return fail(PHONLP_ERR_LAUNCH, "mst_one_root: cannot raise the dynamic LDS limit");
-        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+        attr_once.mark(dev);
     }
     const dim3 grid(a.fb_list ? (a.B < 16 ? a.B : 16) : a.B);
     if (a.L <= 64) hipLaunchKernelGGL(mst_wave_kernel<1>, grid, dim3(256), w.total, stream, a, w.stack_cap);
