@@ -73,6 +73,34 @@ def test_argument_errors_without_gpu(heads_lib):
     assert heads_lib.phonlp_pos_loss(one, one, one, 1, 2, 24, 1, one, one, 8, None) == -2
     assert heads_lib.phonlp_pos_loss_grad(one, one, one, None, 1, 2, 24, 1, one, None) == -1
     assert heads_lib.phonlp_biaffine_label_ws_bytes(256, 128, 400, 33) == 256 * 128 * (2 * 408 + 33 * 408) * 4
+    # this round's entries: packed rows, device-side unsort, parser-loss gradient, the no-workspace CRF gradient
+    assert heads_lib.phonlp_pack_descriptor(None, 1, 4, None, None, 4, None) == -1
+    assert b"pack_descriptor" in heads_lib.phonlp_last_error()
+    assert heads_lib.phonlp_pack_rows(one, 6, 8, one, 4, 6, one, None) == -1  # W % 4 != 0
+    assert heads_lib.phonlp_pack_rows(one, 8, 8, one, 0, 8, one, None) == -1  # no rows
+    assert heads_lib.phonlp_unpack_rows(None, one, 4, 8, one, 8, None) == -1
+    assert heads_lib.phonlp_scatter_rows(one, 2, 8, 8, one, one, 8, 4, None, None, None) == -1  # col0 >= Ls
+    # packed arc scores: more live rows than B*L, n_scorers not 1 or 3, workspace too small
+    assert heads_lib.phonlp_biaffine_arc_scores_packed(one, 100, one, one, one, 2, 8, 400, 3, 1, 1, one, one, None, one,
+                                                       1 << 30, None) == -1
+    assert heads_lib.phonlp_biaffine_arc_scores_packed(one, 10, one, one, one, 2, 8, 400, 2, 0, 0, one, one, None, one,
+                                                       1 << 30, None) == -1
+    assert heads_lib.phonlp_biaffine_arc_scores_packed(one, 10, one, one, one, 2, 8, 400, 3, 1, 1, one, one, None, one,
+                                                       16, None) == -2
+    assert heads_lib.phonlp_label_at_heads_fused_packed(one, one, one, one, one, one, one, None, one, 10, 2, 8, 400, 33, one,
+                                                        None, one, 1 << 30, None) == -1  # rowmap missing
+    assert heads_lib.phonlp_label_at_heads_fused_packed(one, one, one, one, one, one, one, one, one, 10, 2, 8, 400, 33, one,
+                                                        None, one, 16, None) == -2
+    assert heads_lib.phonlp_dep_loss_grad(one, None, one, one, one, one, one, 1, 2, 400, 33, 1, 0, 2.0, one, one, one, one,
+                                          None) == -1  # linearization term without the raw scorer outputs
+    assert b"dep_loss_grad" in heads_lib.phonlp_last_error()
+    assert heads_lib.phonlp_dep_loss_grad(one, one, one, one, one, one, one, 1, 2, 400, 33, 1, 1, 0.0, one, one, one, one,
+                                          None) == -1
+    assert heads_lib.phonlp_crf_nll_grad_static_max_bytes() == 4 << 20
+    assert heads_lib.phonlp_crf_nll_grad_static(one, one, None, None, one, 4096, 4, 64, 1.0, one, one, None) == -4  # B*T*T*4 > 4 MiB
+    assert heads_lib.phonlp_get_mst_fast_path() in (0, 1)
+    assert heads_lib.phonlp_mst_fallback_counter_offset(256, 128) > 0 and heads_lib.phonlp_mst_fallback_counter_offset(64, 512) > 0
+    assert heads_lib.phonlp_mst_fallback_counter_offset(8, 136) == -1  # the reference-order kernel alone decodes this length
 
 
 def test_missing_library_fails_loudly(monkeypatch):
