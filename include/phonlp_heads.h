@@ -222,8 +222,10 @@ int phonlp_label_at_heads_rows4(const float *T4, const float *XF, const int32_t 
  * in the accumulators, so T (1.8 GB at B=256, L=128) is neither written nor read; needs the heads first, i.e. runs
  * after the MST.  The product is taken transposed (weight rows x words: an accumulator lane then holds one word and
  * sixteen head features, and the contraction needs no cross-lane sums); the heads' features are gathered and transposed
- * into the workspace first.  Wbtcp/wbtc_inv = split image of the [O*KPC, KP] matrix whose row o*KPC + d2 is row o*KP + d2
- * of the phonlp_pack_bilinear image (KPC = phonlp_label_kpc(H) = KP rounded up to 32; the added rows zero).  Same scores
+ * into the workspace first.  Wbtcp/wbtc_inv = split image of the [O*KPC, KP] matrix whose row (blk*O + o)*32 + r is row
+ * o*KP + 32*blk + r of the phonlp_pack_bilinear image (KPC = phonlp_label_kpc(H) = KP rounded up to 32, blk < KPC/32,
+ * r < 32; rows past KP zero): relations interleaved by blocks of 32 head features, so that the relations a wavefront
+ * scores share one block of the heads' features.  wbtc_inv and the workspace must be 16-byte aligned.  Same scores
  * as phonlp_label_at_heads to fp32 rounding (another, fixed, summation order).  best_opt may be NULL. */
 int phonlp_label_kpc(int H);
 size_t phonlp_label_at_heads_fused_ws_bytes(int B, int L, int H, int O);

@@ -21,11 +21,13 @@ struct LinearArgs {
     const float *row_scale, *col_scale;
     int rows4;  // linear_f16x3.hip: 1 = write Y in the "rows interleaved by 4" layout straight from the accumulators;
                 // 2 = labels-at-heads epilogue (no Y; rows = (relation, head feature) weight rows, columns = words):
-                //     P[row/32][col] = sum over the tile's 32 rows of C[row][col] * x2[(row % kpc) * ldx2 + col]
-    const float *x2;       // mode 2: head-side features of every word's head, transposed: [kpx][N], row pitch ldx2 floats
+                //     P[row/32][col] = sum over the tile's 32 rows of C[row][col] * x2[((d2/4) * ldx2 + col) * 4 + d2%4],
+                //     d2 = 32 * (row / 32 / nrel) + row % 32
+    const float *x2;       // mode 2: head-side features of every word's head, transposed by fours: [kpx/4][ldx2][4]
     float *P;              // mode 2: [M/32][N]
     long ldx2;
-    int kpc, kpx;          // mode 2: rows per relation (multiple of 32) and how many of them are real
+    int kpc, kpx, nrel;    // mode 2: rows per relation (multiple of 32), how many of them are real, relations; weight row
+                           //         (blk * nrel + o) * 32 + d2 % 32 holds relation o, head feature d2 = 32 blk + d2 % 32
     long bsx, bsw, bsy;  // batched launch (gridDim.y > 1): float strides of X, W, Y between the items
     int gm;   // linear_f16x3.hip: row tiles per group of the tile walk (0 = 4)
     int dbg;  // -DPHONLP_ABLATION builds only (PHONLP_X3_ABLATION): 1 = epilogue without its global stores, 2 = no epilogue

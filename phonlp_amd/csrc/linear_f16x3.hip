@@ -22,6 +22,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "linear_args.h"
 
 namespace phonlp {
@@ -123,15 +125,18 @@ __device__ __forceinline__ void rows4_epilogue(f32x16 (&acc)[TM][TN], const Line
 }
 
 // Labels-at-heads epilogue (mode 2): the tile of T never leaves the chip.  The product is taken TRANSPOSED -- the
-// kernel's row operand is the bilinear weight image (rows = (relation o, head feature d2), kpc rows per relation, kpc a
-// multiple of 32 so a 32-row accumulator tile lies inside one relation) and its column operand the words' X1 image --
+// kernel's row operand is the bilinear weight image (row (blk * O + o) * 32 + d2 % 32 = relation o, head feature
+// d2 = 32 blk + d2 % 32; kpc / 32 blocks, so a 32-row accumulator tile lies inside one relation) and its column operand
+// the words' X1 image --
 // because of where the MFMA leaves the results: a lane holds ONE column (one word) and 16 rows (16 values of d2), so the
 // contraction over d2 with the head's features is a per-lane sum over its own registers, plus one exchange between
 // the two half-waves.  (With words as rows every sum ran across 32 lanes: eleven cross-lane exchanges per tile and
-// 0.40 of the kernel's 1.42 ms.)  The head's features come from x2t[d2][word] -- gathered through the decoded heads
-// and transposed once per batch (gather_heads_t_kernel) -- so a half-wave's load is 128 contiguous bytes.
+// 0.40 of the kernel's 1.42 ms.)  The head's features come from x2t[d2/4][word][d2%4] -- gathered through the decoded
+// heads and transposed once per batch (gather_heads_t_kernel) -- so a lane's four consecutive rows are one float4 and a
+// half-wave's load is 512 contiguous bytes (scalar loads from x2t[d2][word]: 128 per lane and tile, 0.19 of 1.19 ms).
 // P[row/32][word] = this tile's share of score[word][o]; label_reduce_kernel adds the kpc/32 shares of a relation in
-// ascending order, so the sum has one fixed order: deterministic, and the same whatever batch a sentence is decoded in.
+// ascending feature-block order, so the sum has one fixed order: deterministic, and the same whatever batch a sentence
+// is decoded in.
 template <int TM, int TN>
 __device__ __forceinline__ void at_heads_epilogue(f32x16 (&acc)[TM][TN], const LinearArgs &a, int m0, int n0, int wm,
                                                   int wn, int lane) {
@@ -143,43 +148,63 @@ __device__ __forceinline__ void at_heads_epilogue(f32x16 (&acc)[TM][TN], const L
         word[j] = n0 + (wn * TN + j) * 32 + l32;
         cs[j] = word[j] < a.N ? a.col_scale[word[j]] : 0.f;
     }
+    // A 32-row accumulator tile is group grp = row / 32 of the weight image = (feature block grp / O, relation grp % O):
+    // the wave's TM tiles are TM consecutive relations of (nearly always) ONE block of 32 head features, so the heads'
+    // features are loaded once per wave and used by all of them -- with the rows ordered (relation, feature) every tile
+    // re-read its own 32 KB of x2t and the epilogue moved a third as many bytes again as the product's operands.
+    // A lane's 16 registers are four groups of four consecutive rows (d2 = 32 blk + 4 half + 8g + 0..3): one float4 of the
+    // rows-by-4 image of the features and one of the row scales per group; kpx and a.M are multiples of 4 and 32, so a
+    // group is valid or invalid as a whole.
+    const int grp0 = __builtin_amdgcn_readfirstlane((m0 >> 5) + wm * TM);
+    float4 x[TN][4];
+    int cur_blk = -1;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        const int tile_row = m0 + (wm * TM + i) * 32;
-        const int d2b = tile_row % a.kpc + 4 * half;
-        float rs[16];
-        long xo[16];
+        const int grp = grp0 + i, tile_row = grp << 5;
+        const int blk = grp / a.nrel;
+        const bool tv = tile_row < a.M;
+        if (blk != cur_blk) {  // wave-uniform
+            cur_blk = blk;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int o = (r & 3) + 8 * (r >> 2);
-            const int row = tile_row + 4 * half + o, d2 = d2b + o;
-            const bool valid = row < a.M && d2 < a.kpx;
-            rs[r] = valid ? a.row_scale[row] : 0.f;
-            xo[r] = (long)(valid ? d2 : 0) * a.ldx2;
+            for (int g = 0; g < 4; ++g) {
+                const int d2 = blk * 32 + 4 * half + 8 * g;
+                const long xo = (long)(tv && d2 < a.kpx ? d2 >> 2 : 0) * a.ldx2 * 4;
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    x[j][g] = *reinterpret_cast<const float4 *>(a.x2 + (word[j] < a.N ? word[j] : 0) * 4L + xo);
+            }
+        }
+        float4 rs[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const bool valid = tv && blk * 32 + 4 * half + 8 * g < a.kpx;
+            rs[g] = valid ? *reinterpret_cast<const float4 *>(a.row_scale + tile_row + 4 * half + 8 * g)
+                          : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const bool wok = word[j] < a.N;
-            const float *xc = a.x2 + (wok ? word[j] : 0);
-            float x[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) x[r] = xc[xo[r]];
             float sum = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sum += acc[i][j][r] * rs[r] * x[r];
+            for (int g = 0; g < 4; ++g) {  // ascending register index: the order of the sum is part of the result
+                sum += acc[i][j][4 * g + 0] * rs[g].x * x[j][g].x;
+                sum += acc[i][j][4 * g + 1] * rs[g].y * x[j][g].y;
+                sum += acc[i][j][4 * g + 2] * rs[g].z * x[j][g].z;
+                sum += acc[i][j][4 * g + 3] * rs[g].w * x[j][g].w;
+            }
             sum *= cs[j];
             sum += __shfl_xor(sum, 32);  // the rows of the other half-wave
 #ifdef PHONLP_ABLATION
             if (a.dbg == 1 && sum != 1234.5f) continue;
 #endif
-            if (half == 0 && wok && tile_row < a.M) a.P[(long)(tile_row >> 5) * a.N + word[j]] = sum;
+            if (half == 0 && word[j] < a.N && tv) a.P[(long)grp * a.N + word[j]] = sum;
         }
     }
 }
 
 // hrow[m] = row of the head's features for word m = (b, i), 1 <= i < sentlens[b]; -1 elsewhere (ROOT, padding); and
-// x2t[d2][m] = x2[hrow[m]][d2] (0 where there is no head): the head-side features gathered through the decoded heads,
-// transposed so that the epilogue above reads them word-contiguous.  Block = 32 words x 32 features through LDS.
+// x2t[d2 / 4][m][d2 % 4] = x2[hrow[m]][d2] (0 where there is no head; kpx % 4 == 0): the head-side features gathered
+// through the decoded heads, transposed and interleaved by four so that the epilogue above reads a word's four
+// consecutive features as one float4, 512 contiguous bytes per half-wave.  Block = 32 words x 32 features through LDS.
 __global__ __launch_bounds__(1024) void gather_heads_t_kernel(const int32_t *heads, const int32_t *sentlens,
                                                               const float *x2, long ldx2, int M, int L, int kpx,
                                                               int32_t *hrow, float *x2t, const int32_t *rowmap,
@@ -207,10 +232,12 @@ __global__ __launch_bounds__(1024) void gather_heads_t_kernel(const int32_t *hea
     const int h = hr[ty];
     tile[ty][tx] = (h >= 0 && d0 + tx < kpx) ? x2[(long)h * ldx2 + d0 + tx] : 0.f;
     __syncthreads();
-    if (d0 + ty < kpx && m0 + tx < M) x2t[(long)(d0 + ty) * M + m0 + tx] = tile[tx][ty];
+    // rows-by-4 image: x2t[(d2 >> 2) * M + m][d2 & 3]; 128 consecutive threads write 512 contiguous bytes
+    const int f = (threadIdx.x & 3) + 4 * (threadIdx.x >> 7), w = (threadIdx.x >> 2) & 31;
+    if (d0 + f < kpx && m0 + w < M) x2t[((long)((d0 + f) >> 2) * M + m0 + w) * 4 + (f & 3)] = tile[w][f];
 }
 
-// rels[m] = argmax_o sum_{t < gpo} P[o*gpo + t][m] (shares added in ascending t; strict '>' in ascending o), 0 for
+// rels[m] = argmax_o sum_{t < gpo} P[t*O + o][m] (shares added in ascending t; strict '>' in ascending o), 0 for
 // words without a label.  Block = 64 words x 8 relation classes (o mod 8), combined through LDS.
 __global__ __launch_bounds__(512) void label_reduce_kernel(const float *P, const int32_t *hrow, int M, int O, int gpo,
                                                            int32_t *rels, float *best_opt, const int32_t *rowmap) {
@@ -224,7 +251,7 @@ __global__ __launch_bounds__(512) void label_reduce_kernel(const float *P, const
     if (live)
         for (int o = oq; o < O; o += 8) {
             float s = 0.f;
-            for (int t = 0; t < gpo; ++t) s += P[(long)(o * gpo + t) * M + m];
+            for (int t = 0; t < gpo; ++t) s += P[(long)(t * O + o) * M + m];
             if (s > bv) { bv = s; bo = o; }
         }
     sv[oq][lx] = bv;
@@ -262,7 +289,7 @@ __device__ __forceinline__ void lds_dma16(const unsigned char *gptr, unsigned ld
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_addr), "v"(gptr) : "memory", "m0");
 }
 
-template <int TAG, bool PREFETCH>
+template <int TAG, bool PREFETCH, bool ILV = false>
 __global__ __launch_bounds__(256, 2) void linear_f16x3_dma_kernel(LinearArgs a) {
     constexpr int BM = 256, BN = 128, WM = 2, WN = 2, TM = 4, TN = 2, NBUF = 3;
     constexpr int ROWS = BM + BN, BUF = ROWS * 64;
@@ -302,6 +329,11 @@ __global__ __launch_bounds__(256, 2) void linear_f16x3_dma_kernel(LinearArgs a) 
         row = row < a.N ? row : a.N - 1;
         src[q] = reinterpret_cast<const unsigned char *>(a.W) + (long)row * a.ldw + chunk * 16;
     }
+#ifdef PHONLP_ABLATION
+    if (a.dbg == 4)  // timing only: every load from the same 64 bytes (no L2 traffic, same issue count)
+#pragma unroll
+        for (int q = 0; q < 6; ++q) src[q] = reinterpret_cast<const unsigned char *>(a.X) + chunk * 16;
+#endif
     const unsigned lds0 = (unsigned)(uintptr_t)lds + (unsigned)__builtin_amdgcn_readfirstlane(wave) * 1024u;
     auto issue_stage = [&](int st, int buf) {
 #pragma unroll
@@ -356,7 +388,66 @@ __global__ __launch_bounds__(256, 2) void linear_f16x3_dma_kernel(LinearArgs a) 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
-    if constexpr (PREFETCH) {
+    if constexpr (PREFETCH && ILV) {
+        // Register-prefetch loop with the LDS-DMA issues spread between the MFMAs.  The fragments of stage s are in
+        // registers before stage s starts, so behind the barrier at its top buffer s%3 is free: the loads issued DURING
+        // stage s are those of stage s+3 (into buffer s%3), one behind every fourth MFMA, and every load still has between
+        // two and three stages to land.
+        auto pin = [&]() {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(acc[i][j]));
+        };
+        if (nst > 2) issue_stage(2, 2);
+        Frags f0, f1;
+        read_frags(0, f0);
+        auto full = [&](int s, int b0, const Frags &fc, Frags &fn) {  // b0 = s % 3; needs s + 3 < nst
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // stage s+1 landed (s+2 may be in flight)
+            lds_barrier();
+            read_frags(b0 == 2 ? 0 : b0 + 1, fn);
+            asm volatile("" ::: "memory");
+            pin();
+            const long so = (long)(s + 3) * 64;
+            const unsigned ld = lds0 + (unsigned)(b0 * BUF);
+#define PHONLP_X3_HALF(AA, BB, I0, Q)                                                                          \
+    _Pragma("unroll") for (int i = I0; i < I0 + TM / 2; ++i)                                                   \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] = PHONLP_F16_MFMA(fc.AA[i], fc.BB[j], acc[i][j]); \
+    pin();                                                                                                     \
+    lds_dma16(src[Q] + so, ld + Q * 4096);
+            PHONLP_X3_HALF(al, bh, 0, 0)
+            PHONLP_X3_HALF(al, bh, TM / 2, 1)
+            PHONLP_X3_HALF(ah, bl, 0, 2)
+            PHONLP_X3_HALF(ah, bl, TM / 2, 3)
+            PHONLP_X3_HALF(ah, bh, 0, 4)
+            PHONLP_X3_HALF(ah, bh, TM / 2, 5)
+#undef PHONLP_X3_HALF
+        };
+        auto tail = [&](int s, int b0, const Frags &fc, Frags &fn) {
+            if (s + 1 < nst) {
+                if (s + 2 < nst) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                lds_barrier();
+                if (s + 3 < nst) issue_stage(s + 3, b0);
+                read_frags(b0 == 2 ? 0 : b0 + 1, fn);
+            }
+            mma_frags(fc);
+        };
+        int s = 0, b0 = 0;
+        for (; s + 4 < nst; s += 2) {
+            full(s, b0, f0, f1);
+            b0 = b0 == 2 ? 0 : b0 + 1;
+            full(s + 1, b0, f1, f0);
+            b0 = b0 == 2 ? 0 : b0 + 1;
+        }
+        for (; s < nst; s += 2) {
+            tail(s, b0, f0, f1);
+            b0 = b0 == 2 ? 0 : b0 + 1;
+            if (s + 1 < nst) tail(s + 1, b0, f1, f0);
+            b0 = b0 == 2 ? 0 : b0 + 1;
+        }
+        lds_barrier();  // the epilogue's LDS patch aliases the stage buffers
+    } else if constexpr (PREFETCH) {
         // one stage: fetch stage s+2 into the buffer whose readers are all past the previous barrier, publish stage s+1
         // (own pieces landed, then the barrier), prefetch its fragments, multiply stage s.
         auto stage = [&](int s, const Frags &fc, Frags &fn) {
@@ -400,6 +491,56 @@ __global__ __launch_bounds__(256, 2) void linear_f16x3_dma_kernel(LinearArgs a) 
             if (s + 1 < nst) stage(s + 1, f1, f0);
         }
         lds_barrier();  // the epilogue's LDS patch aliases the stage buffers
+    } else if constexpr (ILV) {
+        // The plain loop with the six LDS-DMA issues of stage s+2 spread between the MFMAs of stage s (one behind every
+        // fourth) instead of in a burst at its top: an issue costs the wave 60-180 cycles, and in a burst those add up
+        // to most of a stage's MFMA time during which only the SIMD's other wave can feed the matrix pipe.  The empty
+        // asm "modifying" the accumulators keeps hipcc from regrouping the MFMAs around the (volatile) issues.
+        auto pin = [&]() {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(acc[i][j]));
+        };
+        auto body = [&](int s, int cur, auto issue) {
+            const int nxt2 = cur == 0 ? 2 : cur - 1;
+#ifdef PHONLP_ABLATION
+            const long so = a.dbg == 4 ? 0 : (long)(s + 2) * 64;
+#define PHONLP_X3_SKIP(Q) (a.dbg == 3 && Q >= 3)  // timing only: half of the loads
+#else
+            const long so = (long)(s + 2) * 64;
+#define PHONLP_X3_SKIP(Q) false
+#endif
+            const unsigned ld = lds0 + (unsigned)(nxt2 * BUF);
+            Frags f;
+            read_frags(cur, f);
+#define PHONLP_X3_HALF(AA, BB, I0, Q)                                                                        \
+    _Pragma("unroll") for (int i = I0; i < I0 + TM / 2; ++i)                                                 \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] = PHONLP_F16_MFMA(f.AA[i], f.BB[j], acc[i][j]); \
+    pin();                                                                                                   \
+    if constexpr (decltype(issue)::value) if (!PHONLP_X3_SKIP(Q)) lds_dma16(src[Q] + so, ld + Q * 4096);
+            PHONLP_X3_HALF(al, bh, 0, 0)
+            PHONLP_X3_HALF(al, bh, TM / 2, 1)
+            PHONLP_X3_HALF(ah, bl, 0, 2)
+            PHONLP_X3_HALF(ah, bl, TM / 2, 3)
+            PHONLP_X3_HALF(ah, bh, 0, 4)
+            PHONLP_X3_HALF(ah, bh, TM / 2, 5)
+#undef PHONLP_X3_HALF
+#undef PHONLP_X3_SKIP
+        };
+        int cur = 0, s = 0;
+        for (; s + 2 < nst; ++s) {
+            body(s, cur, std::true_type{});
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // stage s+1 (issued one iteration ago) has landed
+            lds_barrier();
+            cur = cur == 2 ? 0 : cur + 1;
+        }
+        for (; s < nst; ++s) {
+            body(s, cur, std::false_type{});
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lds_barrier();
+            cur = cur == 2 ? 0 : cur + 1;
+        }
     } else {
         int cur = 0;
         for (int s = 0; s < nst; ++s) {
@@ -416,6 +557,214 @@ __global__ __launch_bounds__(256, 2) void linear_f16x3_dma_kernel(LinearArgs a) 
             cur = cur == 2 ? 0 : cur + 1;
         }
     }
+#ifdef PHONLP_ABLATION
+    if (a.dbg == 2) {  // timing only: keep the accumulators alive without the epilogue
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) t += acc[i][j][e];
+        if (t == 1234.5f) a.Y[tid] = t;
+        return;
+    }
+#endif
+    if (a.rows4 == 2) {
+        at_heads_epilogue<TM, TN>(acc, a, m0, n0, wm, wn, lane);
+        return;
+    }
+    if (a.rows4) {
+        rows4_epilogue<TM, TN>(acc, a, m0, n0, wm, wn, lane);
+        return;
+    }
+    linear_epilogue<TM, TN, WM, WN>(acc, reinterpret_cast<float *>(lds), a, m0, n0, wm, wn, lane, wave);
+}
+
+// The WIDE form: 256 x 256 block tile, EIGHT waves of 128 x 64, one workgroup per CU (two waves per SIMD as above), and
+// the operands fetched a k32 PAIR of stages at a time, 128 contiguous bytes per row.
+//
+// Why: with every load served from L1 the fused stage A above runs in 0.83 instead of 1.08 ms (PHONLP_X3_ABLATION=4), i.e.
+// a quarter of its time is the L2 -> LDS path: 8.8 GB per launch in 64-byte half-line requests, every 128-byte line of
+// L2 asked for twice, a stage apart.  Here a line is asked for once (a lane group of eight covers it) and the square
+// tile moves a third fewer bytes per FLOP: a third of the requests.  The price is one barrier domain of eight waves --
+// both waves of a SIMD stop at it together -- but there is one barrier per 48 MFMAs of a wave instead of one per 24.
+//
+// LDS: two pair buffers of 512 rows x 128 bytes (rows 0-255 A tile, 256-511 B tile) = 128 KB.  Row R's eight 16-byte
+// chunks (k16 stage t = chunk / 4; inside it h0-7, l0-7, h8-15, l8-15) are stored at slot chunk ^ ((R >> 1) & 7): with
+// the 128-byte pitch the sixteen rows of a ds_read_b128 lane group ({0-3,12-15,20-27} / {4-11,16-19,28-31} of the 32)
+// then cover all 64 banks.  A wave-load (1 KB) is 8 rows x 128 bytes, lane i writing slot i & 7 of row i >> 3, so it
+// fetches chunk (i & 7) ^ ((R >> 1) & 7): the swizzle is applied on the global side as above.
+//
+// Per pair and wave: wait for the pair's 8 loads (issued during the FIRST half of the previous pair: a whole k16 stage
+// of slack), barrier, 12 ds_read_b128 + 24 MFMAs with the next pair's 8 loads issued one behind every second MFMA of
+// the first sixteen, then 12 ds_read_b128 + 24 MFMAs.  K16 must be a multiple of 32 (the launcher checks).
+template <int TAG>
+__global__ __launch_bounds__(512, 1) void linear_f16x3_wide_kernel(LinearArgs a) {
+    constexpr int BM = 256, BN = 256, WM = 2, WN = 4, TM = 4, TN = 2;
+    constexpr int ROWS = BM + BN, PBUF = ROWS * 128;
+    static_assert(WM * WN * 32 * (TN * 32 + 4) * 4 <= 2 * PBUF, "epilogue patch must fit");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int ntiles = a.num_m * a.num_n;
+    const int npair = a.K >> 5;
+    int m0, n0;
+    {   // as in the kernel above: one tile per block, an XCD's blocks walk GM-tall groups column-major
+        const int xg = blockIdx.x & 7, jl = blockIdx.x >> 3;
+        const int q = ntiles >> 3, r = ntiles & 7;
+        const int t = (xg < r ? xg * (q + 1) : r * (q + 1) + (xg - r) * q) + jl;
+        const int GM = a.gm > 0 ? a.gm : 4;
+        const int per_group = GM * a.num_n;
+        const int g = t / per_group;
+        const int first_m = g * GM;
+        const int gsz = (a.num_m - first_m) < GM ? (a.num_m - first_m) : GM;
+        const int in = t - g * per_group;
+        m0 = (first_m + in % gsz) * BM;
+        n0 = (in / gsz) * BN;
+    }
+    // wave-load u = 8q + wave (q = 0..7) fills rows 8u .. 8u+7 of the pair image (A: q < 4, B: q >= 4)
+    const int lr = lane >> 3;
+    const int chunk = (lane & 7) ^ (((wave & 1) << 2) + (lane >> 4));  // (R >> 1) & 7 with R = 64q + 8 wave + lr
+    const unsigned char *src[8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int row = m0 + 64 * q + 8 * wave + lr;
+        row = row < a.M ? row : a.M - 1;
+        src[q] = reinterpret_cast<const unsigned char *>(a.X) + (long)row * a.ldx + chunk * 16;
+    }
+#pragma unroll
+    for (int q = 4; q < 8; ++q) {
+        int row = n0 + 64 * (q - 4) + 8 * wave + lr;
+        row = row < a.N ? row : a.N - 1;
+        src[q] = reinterpret_cast<const unsigned char *>(a.W) + (long)row * a.ldw + chunk * 16;
+    }
+#ifdef PHONLP_ABLATION
+    if (a.dbg == 4)  // timing only: every load from the same 128 bytes
+#pragma unroll
+        for (int q = 0; q < 8; ++q) src[q] = reinterpret_cast<const unsigned char *>(a.X) + chunk * 16;
+#endif
+    const unsigned lds0 = (unsigned)(uintptr_t)lds + (unsigned)__builtin_amdgcn_readfirstlane(wave) * 1024u;
+
+    const int r = lane & 31, hh = lane >> 5;
+    const int sw = (r >> 1) & 7;
+    // byte offsets inside a row of the four fragment kinds of k16 stage 0 (stage 1: ^ 64)
+    const int off_h = ((2 * hh) ^ sw) << 4, off_l = ((2 * hh + 1) ^ sw) << 4;
+    const int a_ofs = (wm * 128 + r) * 128;
+    const int b_ofs = (BM + wn * 64 + r) * 128;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    struct Frags {
+        u32x4 ah[TM], al[TM], bh[TN], bl[TN];
+    };
+    auto read_frags = [&](const unsigned char *buf, int t, Frags &f) {
+        const int oh = off_h ^ (t << 6), ol = off_l ^ (t << 6);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            f.bh[j] = *reinterpret_cast<const u32x4 *>(buf + b_ofs + j * 4096 + oh);
+            f.bl[j] = *reinterpret_cast<const u32x4 *>(buf + b_ofs + j * 4096 + ol);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            f.al[i] = *reinterpret_cast<const u32x4 *>(buf + a_ofs + i * 4096 + ol);
+            f.ah[i] = *reinterpret_cast<const u32x4 *>(buf + a_ofs + i * 4096 + oh);
+        }
+    };
+    auto pin = [&]() {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(acc[i][j]));
+    };
+    auto mma_frags = [&](const Frags &f) {  // smallest terms first
+#define PHONLP_X3_ROUND(AA, BB)                      \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)   \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] = PHONLP_F16_MFMA(f.AA[i], f.BB[j], acc[i][j]);
+        PHONLP_X3_ROUND(al, bh)
+        PHONLP_X3_ROUND(ah, bl)
+        PHONLP_X3_ROUND(ah, bh)
+#undef PHONLP_X3_ROUND
+    };
+    auto issue_pair = [&](int p, int pb) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) lds_dma16(src[q] + (long)p * 128, lds0 + (unsigned)(pb * PBUF + q * 8192));
+    };
+    // Software pipeline over the k16 stages (F = fragments of a pair's stage 0, G = of its stage 1; a stage = three rounds
+    // of 8 MFMAs: al.bh, ah.bl, ah.bh):
+    //   rounds 1-2 of F | read G | round 3 of F | rounds 1-2 of G | wait for pair p+1 + barrier | read the next F |
+    //   round 3 of G with the 8 loads of pair p+2 between its MFMAs
+    // so every fragment read has 8 MFMAs (256+ cycles of the matrix pipe) between its issue and its first use, and a
+    // pair's loads have the 40 MFMAs up to the next barrier to land.
+#define PHONLP_X3_ROW(FR, AA, BB, I) \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[I][j] = PHONLP_F16_MFMA(FR.AA[I], FR.BB[j], acc[I][j]);
+#define PHONLP_X3_ROUND(FR, AA, BB)                \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] = PHONLP_F16_MFMA(FR.AA[i], FR.BB[j], acc[i][j]);
+    Frags F, G;
+    auto body = [&](int p, auto more, auto more2) {
+        constexpr bool MORE = decltype(more)::value, MORE2 = decltype(more2)::value;  // pairs p+1 / p+2 exist
+        const int pb = p & 1;
+        const unsigned char *buf = lds + pb * PBUF;
+        PHONLP_X3_ROUND(F, al, bh)
+        PHONLP_X3_ROUND(F, ah, bl)
+        pin();
+        read_frags(buf, 1, G);
+        pin();
+        PHONLP_X3_ROUND(F, ah, bh)
+        pin();
+        PHONLP_X3_ROUND(G, al, bh)
+        PHONLP_X3_ROUND(G, ah, bl)
+        pin();
+        if constexpr (MORE) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // pair p+1 (issued 40+ MFMAs ago) has landed
+            lds_barrier();  // ... everyone's; and everyone has read this pair's fragments: buffer pb is free
+            read_frags(lds + (pb ^ 1) * PBUF, 0, F);
+            pin();
+        }
+        if constexpr (MORE2) {  // round 3 of G with the loads of pair p+2 (into this pair's buffer), one behind every MFMA
+#ifdef PHONLP_ABLATION
+            const long so = a.dbg == 4 ? 0 : (long)(p + 2) * 128;
+#else
+            const long so = (long)(p + 2) * 128;
+#endif
+            const unsigned ld = lds0 + (unsigned)(pb * PBUF);
+#define PHONLP_X3_ONE_DMA(I, J, Q)                                      \
+    acc[I][J] = PHONLP_F16_MFMA(G.ah[I], G.bh[J], acc[I][J]);           \
+    asm volatile("" : "+v"(acc[I][J]));                                 \
+    lds_dma16(src[Q] + so, ld + Q * 8192);
+            PHONLP_X3_ONE_DMA(0, 0, 0)
+            PHONLP_X3_ONE_DMA(0, 1, 1)
+            PHONLP_X3_ONE_DMA(1, 0, 2)
+            PHONLP_X3_ONE_DMA(1, 1, 3)
+            PHONLP_X3_ONE_DMA(2, 0, 4)
+            PHONLP_X3_ONE_DMA(2, 1, 5)
+            PHONLP_X3_ONE_DMA(3, 0, 6)
+            PHONLP_X3_ONE_DMA(3, 1, 7)
+#undef PHONLP_X3_ONE_DMA
+        } else {
+            PHONLP_X3_ROUND(G, ah, bh)
+        }
+    };
+    issue_pair(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+    read_frags(lds, 0, F);
+    if (npair > 1) issue_pair(1, 1);
+    int p = 0;
+    for (; p + 2 < npair; ++p) body(p, std::true_type{}, std::true_type{});
+    if (p + 1 < npair) { body(p, std::true_type{}, std::false_type{}); ++p; }
+    body(p, std::false_type{}, std::false_type{});
+#undef PHONLP_X3_ROW
+#undef PHONLP_X3_ROUND
+    lds_barrier();  // the epilogue's LDS patch aliases the pair buffers
 #ifdef PHONLP_ABLATION
     if (a.dbg == 2) {  // timing only: keep the accumulators alive without the epilogue
         float t = 0.f;
@@ -458,7 +807,11 @@ int launch_linear_f16x3(const char *tag, const void *Xp, long pitch_x, const flo
     int attr_dev;
     if (attr_once.pending(&attr_dev)) {
         const void *fns[] = {(const void *)linear_f16x3_dma_kernel<0, true>, (const void *)linear_f16x3_dma_kernel<1, true>,
-                             (const void *)linear_f16x3_dma_kernel<0, false>, (const void *)linear_f16x3_dma_kernel<1, false>};
+                             (const void *)linear_f16x3_dma_kernel<0, false>, (const void *)linear_f16x3_dma_kernel<1, false>,
+                             (const void *)linear_f16x3_dma_kernel<0, false, true>,
+                             (const void *)linear_f16x3_dma_kernel<1, false, true>,
+                             (const void *)linear_f16x3_dma_kernel<0, true, true>,
+                             (const void *)linear_f16x3_dma_kernel<1, true, true>};
         for (const void *f : fns)
             if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DMA) != hipSuccess)
                 return fail(PHONLP_ERR_LAUNCH, "linear_split: cannot raise the dynamic LDS limit");
@@ -473,20 +826,47 @@ int launch_linear_f16x3(const char *tag, const void *Xp, long pitch_x, const flo
     if (at_heads) {
         a.rows4 = 2;
         a.x2 = at_heads->x2; a.P = at_heads->P; a.ldx2 = at_heads->ldx2;
-        a.kpc = at_heads->kpc; a.kpx = at_heads->kpx;
+        a.kpc = at_heads->kpc; a.kpx = at_heads->kpx; a.nrel = at_heads->nrel;
         a.gm = at_heads->gm;
         static const int gm_env = getenv("PHONLP_X3_GM") ? atoi(getenv("PHONLP_X3_GM")) : 0;  // A/B: row tiles per walk group
         if (gm_env > 0) a.gm = gm_env;
     }
     if (rows4 == 1 && (sentlens || relu || ((uintptr_t)Y & 15)))
         return fail(PHONLP_ERR_SHAPE, "linear_split: the rows-by-4 output takes no activation / padding mask");
+    // the wide form (256 x 256 tile, k32 pairs): PHONLP_X3_WIDE bit 0 = the fused stage A, bit 1 = every other layer (A/B)
+    static const int wide_env = getenv("PHONLP_X3_WIDE") ? atoi(getenv("PHONLP_X3_WIDE")) : 1;
+    if ((K16 & 31) == 0 && (wide_env & (at_heads ? 1 : 2))) {
+        constexpr int LDS_WIDE = 2 * 512 * 128;
+        static PerDeviceOnce wide_once;
+        int wdev;
+        if (wide_once.pending(&wdev)) {
+            const void *wf[] = {(const void *)linear_f16x3_wide_kernel<0>, (const void *)linear_f16x3_wide_kernel<1>};
+            for (const void *f : wf)
+                if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WIDE) != hipSuccess)
+                    return fail(PHONLP_ERR_LAUNCH, "linear_split: cannot raise the dynamic LDS limit");
+            wide_once.mark(wdev);
+        }
+        a.num_n = ceil_div(N, 256);
+        ProfScope psw(tag, stream);
+        const dim3 gw(a.num_m * a.num_n);
+        if (stage_a) hipLaunchKernelGGL((linear_f16x3_wide_kernel<1>), gw, dim3(512), LDS_WIDE, stream, a);
+        else hipLaunchKernelGGL((linear_f16x3_wide_kernel<0>), gw, dim3(512), LDS_WIDE, stream, a);
+        return check_launch("linear_f16x3_wide_kernel");
+    }
     ProfScope ps(tag, stream);
     const dim3 g(a.num_m * a.num_n);
     // the register-prefetch loop wins on long K (W1/W2 layers), the plain loop on short K (stage A): K16 picks
     // (PHONLP_X3_PREFETCH=0/1 forces one form, A/B only)
     static const int pf_env = getenv("PHONLP_X3_PREFETCH") ? atoi(getenv("PHONLP_X3_PREFETCH")) : -1;
     const bool prefetch = pf_env >= 0 ? pf_env != 0 : K16 >= 512;
-    if (prefetch) {
+    static const int ilv_env = getenv("PHONLP_X3_ILV") ? atoi(getenv("PHONLP_X3_ILV")) : 3;  // A/B: LDS-DMA issues between the MFMAs
+    if (!prefetch && (ilv_env & 1)) {
+        if (stage_a) hipLaunchKernelGGL((linear_f16x3_dma_kernel<1, false, true>), g, dim3(256), LDS_DMA, stream, a);
+        else hipLaunchKernelGGL((linear_f16x3_dma_kernel<0, false, true>), g, dim3(256), LDS_DMA, stream, a);
+    } else if (prefetch && (ilv_env & 2)) {
+        if (stage_a) hipLaunchKernelGGL((linear_f16x3_dma_kernel<1, true, true>), g, dim3(256), LDS_DMA, stream, a);
+        else hipLaunchKernelGGL((linear_f16x3_dma_kernel<0, true, true>), g, dim3(256), LDS_DMA, stream, a);
+    } else if (prefetch) {
         if (stage_a) hipLaunchKernelGGL((linear_f16x3_dma_kernel<1, true>), g, dim3(256), LDS_DMA, stream, a);
         else hipLaunchKernelGGL((linear_f16x3_dma_kernel<0, true>), g, dim3(256), LDS_DMA, stream, a);
     } else {
@@ -568,6 +948,8 @@ static int label_at_heads_fused_run(const void *X1p, const float *x1_inv, const 
                                     const int32_t *rowmap, const int32_t *off, int H, int O, int32_t *rels,
                                     float *best_opt, void *ws, hipStream_t st) {
     const int KP = kp_of(H), K16 = (KP + 15) / 16 * 16, KPC = phonlp_label_kpc(H);
+    if (((uintptr_t)wbtc_inv & 15) || ((uintptr_t)ws & 15))  // the epilogue reads the row scales and x2t as float4
+        return fail(PHONLP_ERR_SHAPE, "label_at_heads_fused: wbtc_inv and the workspace must be 16-byte aligned");
     int32_t *hrow = (int32_t *)ws;
     float *P = (float *)((char *)ws + align_up((size_t)M * sizeof(int32_t), 256));
     float *x2t = (float *)((char *)P + align_up((size_t)O * (KPC / 32) * M * sizeof(float), 256));
@@ -585,7 +967,7 @@ static int label_at_heads_fused_run(const void *X1p, const float *x1_inv, const 
     }
     // transposed product: rows = the weight image's (relation, head feature) rows, columns = words
     LinearArgs ah{};
-    ah.x2 = x2t; ah.ldx2 = M; ah.P = P; ah.kpc = KPC; ah.kpx = KP;
+    ah.x2 = x2t; ah.ldx2 = M; ah.P = P; ah.kpc = KPC; ah.kpx = KP; ah.nrel = O;
     int rc = launch_linear_f16x3("linear:label_stage_a", Wbtcp, 4L * K16, wbtc_inv, X1p, 4L * K16, x1_inv, nullptr, nullptr,
                                  0, O * KPC, M, K16, 0, nullptr, 0, st, nullptr, 0, &ah);
     if (rc) return rc;

@@ -169,11 +169,12 @@ class HeadWeights:
 
     @staticmethod
     def _pad_relations(Wbt: torch.Tensor, H: int, O: int) -> torch.Tensor:
-        """[O*KP, KP] -> [O*KPC, KP]: row o*KPC + d2 = row o*KP + d2, added rows zero (phonlp_label_at_heads_fused)."""
+        """[O*KP, KP] -> [O*KPC, KP] for phonlp_label_at_heads_fused: every relation's rows padded with zero rows to KPC
+        (a multiple of 32) and ordered by blocks of 32 head features: row (blk*O + o)*32 + r = row o*KP + 32*blk + r."""
         KP, KPC = ops.kp(H), ops.label_kpc(H)
         out = torch.zeros((O, KPC, KP), dtype=Wbt.dtype, device=Wbt.device)
         out[:, :KP] = Wbt.view(O, KP, KP)
-        return out.view(O * KPC, KP)
+        return out.view(O, KPC // 32, 32, KP).permute(1, 0, 2, 3).contiguous().view(O * KPC, KP)
 
 
 class TaskHeads:
