@@ -310,6 +310,28 @@ def main():
             torch.cuda.synchronize()
         alone_ms = kt_alone.stats["linear:label_stage_a"][1]
 
+    graph_replay = None
+    if rank == 0 and world == 1 and os.environ.get("PHONLP_BENCH_GRAPH", "1") == "1":
+        # the same step (without the eval-count kernels) captured once as a HIP graph and replayed, against eager launches
+        # of the same work; untimed extra, reported beside the headline number (which stays the eager step: its dominant
+        # kernel is bracketed by HIP events on its launch stream, which a graph replay does not allow)
+        cs = heads.capture(B, L)
+        cs.enc_dep.copy_(enc_dep); cs.lens_dep.copy_(ld); cs.enc_tag.copy_(enc_tag); cs.lens_tag.copy_(lt)
+        def timed(fn, n):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n * 1e3
+        n_g = max(args.steps, 4)
+        graph_replay = {"ms_per_step": timed(cs.replay, n_g),
+                        "eager_ms_per_step_same_work": timed(lambda: heads.annotate_batch(enc_dep, ld, enc_tag, lt), n_g),
+                        "note": "TaskHeads.capture(B, L).replay(): the step's launches on three streams as one hipGraphLaunch; "
+                                "both figures without the eval-count kernels of the headline step"}
+
     if rank == 0:
         fl = algorithmic_flops()
         sent = B * args.steps * world
@@ -328,7 +350,8 @@ def main():
                        "tests/test_gpu_parity.py::test_engines_against_fp64); small layers and stage B run bf16x6"}
         short = {0: "f32 MFMA", 1: "bf16x6", 2: "f16x3"}
         kern = {0: "linear_kernel<128,128,2,2,1,0>", 1: "linear_split256_kernel<1>",
-                2: "linear_f16x3_dma_kernel<1, false>" + (" with the labels-at-heads epilogue (T never stored)" if fused else "")}
+                2: ("linear_f16x3_wide_kernel<1> with the labels-at-heads epilogue (T never stored)" if fused else
+                    "linear_f16x3_dma_kernel<1, false, true>")}
         peak_note = {0: "dense fp32 MFMA peak",
                      1: "algorithmic (fp32-equivalent) TFLOP/s; engine 1 peak = 2500 bf16 dense / 6 products",
                      2: "algorithmic (fp32-equivalent) TFLOP/s; engine 2 peak = 2500 f16 dense / 3 products"}
@@ -390,6 +413,7 @@ def main():
                              "note": "the same kernel, shapes and weights with the chip to itself (X1 = relu(N(0,1))), "
                                      "8 launches after the timed region; `achieved` above is the in-step figure"}},
             "roofline_secondary": secondary, "roofline_secondary_note": sec_note,
+            "graph_replay": graph_replay,
             "kernels_ms": kernels_ms,
             "kernels_ms_note": "mean per launch, every launch bracketed by HIP events" +
                                ("" if time_all else " in an extra untimed pass after the timed region (inside it only "
