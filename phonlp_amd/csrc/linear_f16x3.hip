@@ -615,7 +615,7 @@ __global__ __launch_bounds__(512, 1) void linear_f16x3_wide_kernel(LinearArgs a)
         const int xg = blockIdx.x & 7, jl = blockIdx.x >> 3;
         const int q = ntiles >> 3, r = ntiles & 7;
         const int t = (xg < r ? xg * (q + 1) : r * (q + 1) + (xg - r) * q) + jl;
-        const int GM = a.gm > 0 ? a.gm : 4;
+        const int GM = a.gm > 0 ? a.gm : 8;  // measured: 8 rows of tiles per group 1 % ahead of 4, 16 level, 1 / 54 3-5 % behind
         const int per_group = GM * a.num_n;
         const int g = t / per_group;
         const int first_m = g * GM;
