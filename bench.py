@@ -241,7 +241,10 @@ def main():
 
     engine = ops.get_gemm_engine()
     other_ms = {}
-    if world == 1:  # the other matrix engines on the same step, reported beside the headline number
+    # PHONLP_BENCH_EXTRAS=0 (tools/profile_round.sh): only the timed steps and the kernels_ms pass, so that a profiler's
+    # per-kernel averages over the whole command are those of the step
+    EXTRAS = os.environ.get("PHONLP_BENCH_EXTRAS", "1") == "1"
+    if world == 1 and EXTRAS:  # the other matrix engines on the same step, reported beside the headline number
         for other in (0, 1, 2):
             if other == engine:
                 continue
@@ -293,7 +296,7 @@ def main():
 
     alone_ms = None
     fused = heads.cfg["label_fused"]
-    if rank == 0 and engine == 2:  # the dominant kernel with the chip to itself (same shapes and weights; untimed extra)
+    if rank == 0 and engine == 2 and EXTRAS:  # the dominant kernel with the chip to itself (same shapes and weights; untimed extra)
         w = heads.w
         KP = ops.kp(H)
         x1 = torch.relu(torch.randn(B * L, KP, device=dev))
@@ -316,7 +319,7 @@ def main():
         alone_ms = kt_alone.stats["linear:label_stage_a"][1]
 
     graph_replay = None
-    if rank == 0 and world == 1 and os.environ.get("PHONLP_BENCH_GRAPH", "1") == "1":
+    if rank == 0 and world == 1 and EXTRAS and os.environ.get("PHONLP_BENCH_GRAPH", "1") == "1":
         # the same step (without the eval-count kernels) captured once as a HIP graph and replayed, against eager launches
         # of the same work; untimed extra, reported beside the headline number (which stays the eager step: its dominant
         # kernel is bracketed by HIP events on its launch stream, which a graph replay does not allow)
@@ -338,7 +341,7 @@ def main():
                                 "both figures without the eval-count kernels of the headline step"}
 
     other_form = None
-    if rank == 0 and world == 1:  # the other step form on the same batches (extra pass, same fences)
+    if rank == 0 and world == 1 and EXTRAS:  # the other step form on the same batches (extra pass, same fences)
         streaming[0] = 1 - STREAMING
         for _ in range(2):
             step()

@@ -7,6 +7,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 B=$GRAFT_REPO_ROOT/bench.py
+export PHONLP_BENCH_EXTRAS=0   # only the timed steps + the kernels_ms pass: per-kernel averages are those of the step
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats --output-format csv -- python3 $B --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/stats.err || exit 1
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o fetch --output-format csv -- python3 $B --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/fetch.err || exit 1
 timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o write --output-format csv -- python3 $B --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/write.err || exit 1
