@@ -3,12 +3,19 @@ usage: python tools/f16x3_probe.py [reps]"""
 import os, sys, time, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+if os.environ.get("PHONLP_X3_ABLATION"):  # the ablation branches only exist in the -DPHONLP_ABLATION build (timing only)
+    from phonlp_amd import _lib as _l
+    _l.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libphonlp_heads_ablation.so")
 from phonlp_amd import ops
 from phonlp_amd._lib import lib, check
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 dev = torch.device("cuda:0")
 P = lambda t: ctypes.c_void_p(t.data_ptr())
-for (M, N, K, ldk) in [(32768, 13464, 401, 408), (32768, 2448, 868, 868), (32768, 816, 868, 868), (4096, 4096, 4096, 4096), (1000, 333, 100, 100)]:
+shapes = [(32768, 13464, 401, 408), (32768, 2448, 868, 868), (32768, 816, 868, 868), (4096, 4096, 4096, 4096), (1000, 333, 100, 100)]
+if os.environ.get("PROBE_SHAPE"):  # "M N K ldk"
+    shapes = [tuple(int(v) for v in os.environ["PROBE_SHAPE"].split())]
+only_x3 = os.environ.get("PROBE_ONLY_X3") == "1"
+for (M, N, K, ldk) in shapes:
     g = torch.Generator(device="cpu").manual_seed(M + N + K)
     x = torch.zeros(M, ldk); x[:, :K] = torch.randn(M, K, generator=g) * torch.exp(2 * torch.randn(M, 1, generator=g))
     w = torch.zeros(N, ldk); w[:, :K] = torch.randn(N, K, generator=g) * 0.05
@@ -28,7 +35,7 @@ for (M, N, K, ldk) in [(32768, 13464, 401, 408), (32768, 2448, 868, 868), (32768
               f"max|err|/sum|a||b| = {(err/scale).max().item():.3e}  rms rel = {(err.pow(2).mean().sqrt()/ref.pow(2).mean().sqrt()).item():.3e}",
               flush=True)
     y = torch.empty(M, N, device=dev)
-    for eng in (0, 1):
+    for eng in (() if only_x3 else (0, 1)):
         ops.set_gemm_engine(eng)
         run = lambda: check(lib().phonlp_linear(P(x), ldk, P(w), ldk, None, P(y), N, M, N, ldk, 0, None, 0, None), "linear")
         dt = timeit(run)
