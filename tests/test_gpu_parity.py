@@ -679,7 +679,10 @@ def test_label_at_heads_matches_dense_label_scorer(dev, engine, B, L, H, O):
                 assert abs(float(col[got[b, i]]) - float(col[want[b, i]])) <= tol, (b, i)
 
 
-@pytest.mark.parametrize("B,L,H,O", [(5, 37, 24, 5), (8, 128, 400, 33), (3, 130, 400, 7)])
+@pytest.mark.parametrize("B,L,H,O", [(5, 37, 24, 5), (8, 128, 400, 33), (3, 130, 400, 7),
+                                     # fused form: K16 = 64 / 96 (two / three k32 pairs of the wide kernel), K16 = 48 (not a
+                                     # multiple of 32: the 256x128 kernel), several column tiles, relations not a multiple of 4
+                                     (4, 90, 56, 6), (6, 70, 88, 9), (3, 50, 40, 4)])
 def test_label_rows4_pair_matches_row_major(dev, B, L, H, O):
     """Engine 2's stage A in the 'rows interleaved by 4' layout is the row-major stage A bit for bit (same loop,
     different store), and label_at_heads_rows4 returns what label_at_heads returns on the same T: winning scores to
