@@ -13,7 +13,7 @@ def _batch(B, L, seed, dev):
     return enc_dep.to(dev), ld.to(dev), enc_tag.to(dev), (ld - 1).to(dev)
 
 
-@pytest.mark.parametrize("B,L", [(1, 24), (8, 64), (32, 128)])
+@pytest.mark.parametrize("B,L", [(1, 24), (8, 64), (32, 128), (4, 160)])  # 160: the unfused label path, MST in global memory
 def test_captured_step_matches_eager(B, L):
     from phonlp_amd import HeadWeights, TaskHeads, synthetic as S
     dev = torch.device("cuda:0")
