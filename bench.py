@@ -380,7 +380,7 @@ def main():
                        "tests/test_gpu_parity.py::test_engines_against_fp64); small layers and stage B run bf16x6"}
         short = {0: "f32 MFMA", 1: "bf16x6", 2: "f16x3"}
         kern = {0: "linear_kernel<128,128,2,2,1,0>", 1: "linear_split256_kernel<1>",
-                2: ("linear_f16x3_wide_kernel<1> with the labels-at-heads epilogue (T never stored)" if fused else
+                2: ("linear_f16x3_wide_heads_kernel (persistent 256x256 tiles) with the labels-at-heads epilogue (T never stored)" if fused else
                     "linear_f16x3_dma_kernel<1, false, true>")}
         peak_note = {0: "dense fp32 MFMA peak",
                      1: "algorithmic (fp32-equivalent) TFLOP/s; engine 1 peak = 2500 bf16 dense / 6 products",
@@ -400,7 +400,7 @@ def main():
             "viterbi": B * (L - 1) * T * 4 + T * T * 4 + B * (L - 1) * 4 + B * 4,
             "mst": B * L * L * 4 * 2 + B * L * 4 + B * 4,                         # arc log-probs (read by both decode phases), heads + status out
             "label_at_heads": M_ * O * KP_ * 4 + M_ * KP_ * 4 + M_ * 8,
-            "label_reduce": _lib.lib().phonlp_label_at_heads_fused_ws_bytes(B, L, H, O) + M_ * 8,  # per-tile shares in, ids out
+            "label_reduce": O * (_lib.lib().phonlp_label_kpc(H) // 32) * M_ * 4 + M_ * 4 + M_ * 8,  # per-tile shares + head rows in, ids + scores out
             "tagger_tail": M_ * (U + T + 2) * 4 + M_ * (H + T) * 4,
             "split_rows": M_ * KP_ * 4 * 2,
         }

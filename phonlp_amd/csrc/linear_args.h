@@ -30,6 +30,7 @@ struct LinearArgs {
                            //         (blk * nrel + o) * 32 + d2 % 32 holds relation o, head feature d2 = 32 blk + d2 % 32
     long bsx, bsw, bsy;  // batched launch (gridDim.y > 1): float strides of X, W, Y between the items
     int gm;   // linear_f16x3.hip: row tiles per group of the tile walk (0 = 4)
+    int *tile_ctr;  // mode 2, persistent wide kernel: eight tile counters (one per XCD chunk of the walk), zero at launch
     int dbg;  // -DPHONLP_ABLATION builds only (PHONLP_X3_ABLATION): 1 = epilogue without its global stores, 2 = no epilogue
 };
 

@@ -208,11 +208,12 @@ __device__ __forceinline__ void at_heads_epilogue(f32x16 (&acc)[TM][TN], const L
 __global__ __launch_bounds__(1024) void gather_heads_t_kernel(const int32_t *heads, const int32_t *sentlens,
                                                               const float *x2, long ldx2, int M, int L, int kpx,
                                                               int32_t *hrow, float *x2t, const int32_t *rowmap,
-                                                              const int32_t *off) {
+                                                              const int32_t *off, int *tile_ctr) {
     __shared__ float tile[32][33];
     __shared__ int hr[32];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int m0 = blockIdx.x * 32, d0 = blockIdx.y * 32;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 8) tile_ctr[threadIdx.x] = 0;  // the persistent stage A's counters
     if (ty == 0) {
         const int m = m0 + tx;
         int v = -1;
@@ -596,9 +597,8 @@ __global__ __launch_bounds__(256, 2) void linear_f16x3_dma_kernel(LinearArgs a) 
 // then cover all 64 banks.  A wave-load (1 KB) is 8 rows x 128 bytes, lane i writing slot i & 7 of row i >> 3, so it
 // fetches chunk (i & 7) ^ ((R >> 1) & 7): the swizzle is applied on the global side as above.
 //
-// Per pair and wave: wait for the pair's 8 loads (issued during the FIRST half of the previous pair: a whole k16 stage
-// of slack), barrier, 12 ds_read_b128 + 24 MFMAs with the next pair's 8 loads issued one behind every second MFMA of
-// the first sixteen, then 12 ds_read_b128 + 24 MFMAs.  K16 must be a multiple of 32 (the launcher checks).
+// Per pair and wave: 24 ds_read_b128, 48 MFMAs, 8 LDS-DMA issues, one barrier (schedule: the comment in the kernel).
+// K16 must be a multiple of 32 (the launcher checks).
 template <int TAG>
 __global__ __launch_bounds__(512, 1) void linear_f16x3_wide_kernel(LinearArgs a) {
     constexpr int BM = 256, BN = 256, WM = 2, WN = 4, TM = 4, TN = 2;
@@ -789,6 +789,220 @@ __global__ __launch_bounds__(512, 1) void linear_f16x3_wide_kernel(LinearArgs a)
     linear_epilogue<TM, TN, WM, WN>(acc, reinterpret_cast<float *>(lds), a, m0, n0, wm, wn, lane, wave);
 }
 
+// tile t of the walk (GM-tall groups of row tiles, column-major inside a group) -> its origin
+__device__ __forceinline__ void wide_tile_origin(const LinearArgs &a, int t, int &m0, int &n0) {
+    const int GM = a.gm > 0 ? a.gm : 8;
+    const int per_group = GM * a.num_n;
+    const int g = t / per_group;
+    const int first_m = g * GM;
+    const int gsz = (a.num_m - first_m) < GM ? (a.num_m - first_m) : GM;
+    const int in = t - g * per_group;
+    m0 = (first_m + in % gsz) * 256;
+    n0 = (in / gsz) * 256;
+}
+
+// The wide kernel as a PERSISTENT workgroup for the labels-at-heads epilogue (which needs no LDS): one workgroup per
+// CU takes tile after tile of its XCD's chunk of the walk from a counter (a.tile_ctr[8], zeroed by the launch in front:
+// gather_heads_t_kernel), and the operand loads of a tile's first two pairs are issued during the LAST two pairs of the
+// tile before it, so they land behind that tile's epilogue: no workgroup launch and no exposed first-load latency per
+// tile (27 tiles per CU at the headline shape).  The pair pipeline is the one above, continued across tiles (the
+// buffer parity runs on); the last pair of a tile only takes a barrier where the others wait for the next pair and
+// read its fragments -- those registers are the epilogue's -- and the next tile's first fragments are read behind the
+// epilogue.  Needs a.K / 32 >= 4.  No waiting on other workgroups anywhere: a workgroup that draws a number past its
+// chunk leaves.
+__global__ __launch_bounds__(512, 1) void linear_f16x3_wide_heads_kernel(LinearArgs a) {
+    constexpr int BM = 256, BN = 256, WN = 4, TM = 4, TN = 2;
+    constexpr int ROWS = BM + BN, PBUF = ROWS * 128;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    __shared__ int s_next;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int npair = a.K >> 5;
+    const int xg = blockIdx.x & 7;
+    const int ntiles = a.num_m * a.num_n, q8 = ntiles >> 3, r8 = ntiles & 7;
+    const int chunk0 = xg < r8 ? xg * (q8 + 1) : r8 * (q8 + 1) + (xg - r8) * q8;  // this XCD's tiles: chunk0 .. chunk0 + chunkn
+    const int chunkn = q8 + (xg < r8 ? 1 : 0);
+    if (tid == 0) s_next = atomicAdd(a.tile_ctr + xg, 1);
+    __syncthreads();
+    const int first = __builtin_amdgcn_readfirstlane(s_next);
+    if (first >= chunkn) return;
+    int m0, n0;
+    wide_tile_origin(a, chunk0 + first, m0, n0);
+
+    const int lr = lane >> 3;
+    const int chunk = (lane & 7) ^ (((wave & 1) << 2) + (lane >> 4));
+    const unsigned char *src[8];
+    auto set_src = [&](int mm, int nn) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int row = mm + 64 * q + 8 * wave + lr;
+            row = row < a.M ? row : a.M - 1;
+            src[q] = reinterpret_cast<const unsigned char *>(a.X) + (long)row * a.ldx + chunk * 16;
+        }
+#pragma unroll
+        for (int q = 4; q < 8; ++q) {
+            int row = nn + 64 * (q - 4) + 8 * wave + lr;
+            row = row < a.N ? row : a.N - 1;
+            src[q] = reinterpret_cast<const unsigned char *>(a.W) + (long)row * a.ldw + chunk * 16;
+        }
+#ifdef PHONLP_ABLATION
+        if (a.dbg == 4)  // timing only: every load from the same 128 bytes
+#pragma unroll
+            for (int q = 0; q < 8; ++q) src[q] = reinterpret_cast<const unsigned char *>(a.X) + chunk * 16;
+#endif
+    };
+    set_src(m0, n0);
+    const unsigned lds0 = (unsigned)(uintptr_t)lds + (unsigned)__builtin_amdgcn_readfirstlane(wave) * 1024u;
+
+    const int r = lane & 31, hh = lane >> 5;
+    const int sw = (r >> 1) & 7;
+    const int off_h = ((2 * hh) ^ sw) << 4, off_l = ((2 * hh + 1) ^ sw) << 4;
+    const int a_ofs = (wm * 128 + r) * 128;
+    const int b_ofs = (BM + wn * 64 + r) * 128;
+
+    f32x16 acc[TM][TN];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    };
+    zero_acc();
+
+    struct Frags {
+        u32x4 ah[TM], al[TM], bh[TN], bl[TN];
+    };
+    auto read_frags = [&](const unsigned char *buf, int t, Frags &f) {
+        const int oh = off_h ^ (t << 6), ol = off_l ^ (t << 6);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            f.bh[j] = *reinterpret_cast<const u32x4 *>(buf + b_ofs + j * 4096 + oh);
+            f.bl[j] = *reinterpret_cast<const u32x4 *>(buf + b_ofs + j * 4096 + ol);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            f.al[i] = *reinterpret_cast<const u32x4 *>(buf + a_ofs + i * 4096 + ol);
+            f.ah[i] = *reinterpret_cast<const u32x4 *>(buf + a_ofs + i * 4096 + oh);
+        }
+    };
+    auto pin = [&]() {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(acc[i][j]));
+    };
+#define PHONLP_X3_ROUND(FR, AA, BB)                \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] = PHONLP_F16_MFMA(FR.AA[i], FR.BB[j], acc[i][j]);
+    Frags F, G;
+    // One pair out of buffer pb.  JOIN: 2 = wait for the following pair, barrier, read its first fragments; 3 = barrier
+    // only, and only if `flag`; 0 = nothing.  LOADS: 1 = the pair two ahead (byte offset `so` of the rows in src[]) goes
+    // into this pair's buffer between the last eight MFMAs (the barrier is what frees the buffer); 2 = the same if `flag`
+    // (wave-uniform: the branches hold nothing but the issue -- two code paths with MFMAs in them made hipcc shuffle the
+    // accumulators at the merge and spill a thousand registers); 0 = none.
+    auto body = [&](int pb, long so, auto join, auto loads, bool flag) {
+        constexpr int JOIN = decltype(join)::value, LOADS = decltype(loads)::value;
+        const unsigned char *buf = lds + pb * PBUF;
+        PHONLP_X3_ROUND(F, al, bh)
+        PHONLP_X3_ROUND(F, ah, bl)
+        pin();
+        read_frags(buf, 1, G);
+        pin();
+        PHONLP_X3_ROUND(F, ah, bh)
+        pin();
+        PHONLP_X3_ROUND(G, al, bh)
+        PHONLP_X3_ROUND(G, ah, bl)
+        pin();
+        if constexpr (JOIN == 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lds_barrier();
+            read_frags(lds + (pb ^ 1) * PBUF, 0, F);
+            pin();
+        } else if constexpr (JOIN == 3) {
+            if (flag) lds_barrier();
+        }
+        if constexpr (LOADS != 0) {
+#ifdef PHONLP_ABLATION
+            if (a.dbg == 4) so = 0;
+#endif
+            const unsigned ld = lds0 + (unsigned)(pb * PBUF);
+#define PHONLP_X3_ONE_DMA(I, J, Q)                                      \
+    acc[I][J] = PHONLP_F16_MFMA(G.ah[I], G.bh[J], acc[I][J]);           \
+    asm volatile("" : "+v"(acc[I][J]));                                 \
+    if (LOADS == 1 || flag) lds_dma16(src[Q] + so, ld + Q * 8192);
+            PHONLP_X3_ONE_DMA(0, 0, 0)
+            PHONLP_X3_ONE_DMA(0, 1, 1)
+            PHONLP_X3_ONE_DMA(1, 0, 2)
+            PHONLP_X3_ONE_DMA(1, 1, 3)
+            PHONLP_X3_ONE_DMA(2, 0, 4)
+            PHONLP_X3_ONE_DMA(2, 1, 5)
+            PHONLP_X3_ONE_DMA(3, 0, 6)
+            PHONLP_X3_ONE_DMA(3, 1, 7)
+#undef PHONLP_X3_ONE_DMA
+        } else {
+            PHONLP_X3_ROUND(G, ah, bh)
+        }
+    };
+    using C1 = std::integral_constant<int, 1>;
+    using C2 = std::integral_constant<int, 2>;
+    using C3 = std::integral_constant<int, 3>;
+    // first tile: pairs 0 and 1
+#pragma unroll
+    for (int q = 0; q < 8; ++q) lds_dma16(src[q], lds0 + (unsigned)(q * 8192));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+    read_frags(lds, 0, F);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) lds_dma16(src[q] + 128, lds0 + (unsigned)(PBUF + q * 8192));
+    int pb = 0;
+    for (;;) {
+        int drawn = 0;  // the next tile's number: drawn now, needed npair - 3 pairs from here
+        if (tid == 0) drawn = atomicAdd(a.tile_ctr + xg, 1);
+        for (int p = 0; p + 3 < npair; ++p) {
+            body(pb, (long)(p + 2) * 128, C2{}, C1{}, true);
+            pb ^= 1;
+        }
+        if (tid == 0) s_next = drawn;
+        body(pb, (long)(npair - 1) * 128, C2{}, C1{}, true);  // the tile's last loads; its barrier publishes s_next
+        pb ^= 1;
+        const int nxt = __builtin_amdgcn_readfirstlane(s_next);
+        const bool has_next = nxt < chunkn;
+        int m1 = m0, n1 = n0;
+        if (has_next) {
+            wide_tile_origin(a, chunk0 + nxt, m1, n1);
+            set_src(m1, n1);
+        }
+        body(pb, 0, C2{}, C2{}, has_next);    // pair npair-2: the next tile's pair 0 takes its buffer
+        pb ^= 1;
+        body(pb, 128, C3{}, C2{}, has_next);  // pair npair-1: the next tile's pair 1 takes its buffer
+        pb ^= 1;
+#ifdef PHONLP_ABLATION
+        if (a.dbg == 2) {  // timing only: keep the accumulators alive without the epilogue
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) t += acc[i][j][e];
+            if (t == 1234.5f) a.P[tid] = t;
+        } else
+#endif
+        at_heads_epilogue<TM, TN>(acc, a, m0, n0, wm, wn, lane);
+        if (!has_next) break;
+        zero_acc();
+        m0 = m1;
+        n0 = n1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next tile's pairs 0 and 1 (issued before the epilogue)
+        lds_barrier();
+        read_frags(lds + pb * PBUF, 0, F);
+    }
+#undef PHONLP_X3_ROUND
+}
+
 int launch_linear_f16x3(const char *tag, const void *Xp, long pitch_x, const float *x_inv, const void *Wp, long pitch_w,
                         const float *w_inv, const float *bias, float *Y, long ldy, int M, int N, int K16, int relu,
                         const int32_t *sentlens, int L, hipStream_t stream, const float *pad_bias, int rows4 = 0,
@@ -847,6 +1061,30 @@ int launch_linear_f16x3(const char *tag, const void *Xp, long pitch_x, const flo
             wide_once.mark(wdev);
         }
         a.num_n = ceil_div(N, 256);
+        // persistent form for the labels-at-heads epilogue: at least two tiles per workgroup, four pairs per tile
+        static const int persist_env = getenv("PHONLP_X3_PERSIST") ? atoi(getenv("PHONLP_X3_PERSIST")) : 1;  // A/B
+        const int ntiles_w = a.num_m * a.num_n;
+        if (at_heads && at_heads->tile_ctr && persist_env && (K16 >> 5) >= 4 && ntiles_w >= 16) {
+            static PerDeviceOnce heads_once;
+            static int n_cu[64];
+            int hdev;
+            if (heads_once.pending(&hdev)) {
+                int cus = 0;
+                if (hipFuncSetAttribute((const void *)linear_f16x3_wide_heads_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        LDS_WIDE) != hipSuccess ||
+                    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, hdev) != hipSuccess || cus < 8)
+                    return fail(PHONLP_ERR_LAUNCH, "linear_split: cannot set up the persistent stage A");
+                n_cu[hdev & 63] = cus;
+                heads_once.mark(hdev);
+            }
+            int cur_dev = 0;
+            (void)hipGetDevice(&cur_dev);
+            const int cap = n_cu[cur_dev & 63] & ~7, want = (ntiles_w / 2) & ~7;
+            a.tile_ctr = at_heads->tile_ctr;
+            ProfScope psh(tag, stream);
+            hipLaunchKernelGGL(linear_f16x3_wide_heads_kernel, dim3(want < cap ? want : cap), dim3(512), LDS_WIDE, stream, a);
+            return check_launch("linear_f16x3_wide_heads_kernel");
+        }
         ProfScope psw(tag, stream);
         const dim3 gw(a.num_m * a.num_n);
         if (stage_a) hipLaunchKernelGGL((linear_f16x3_wide_kernel<1>), gw, dim3(512), LDS_WIDE, stream, a);
@@ -940,7 +1178,7 @@ extern "C" size_t phonlp_label_at_heads_fused_ws_bytes(int B, int L, int H, int 
     if (B <= 0 || L <= 0 || H <= 0 || O <= 0) return 0;
     const size_t M = (size_t)B * L;
     return align_up(M * sizeof(int32_t), 256) + align_up((size_t)O * (phonlp_label_kpc(H) / 32) * M * sizeof(float), 256) +
-           align_up((size_t)kp_of(H) * M * sizeof(float), 256);
+           align_up((size_t)kp_of(H) * M * sizeof(float), 256) + 256;  // hrow, P, x2t, tile counters
 }
 
 static int label_at_heads_fused_run(const void *X1p, const float *x1_inv, const void *Wbtcp, const float *wbtc_inv,
@@ -953,6 +1191,7 @@ static int label_at_heads_fused_run(const void *X1p, const float *x1_inv, const 
     int32_t *hrow = (int32_t *)ws;
     float *P = (float *)((char *)ws + align_up((size_t)M * sizeof(int32_t), 256));
     float *x2t = (float *)((char *)P + align_up((size_t)O * (KPC / 32) * M * sizeof(float), 256));
+    int *tile_ctr = (int *)((char *)x2t + align_up((size_t)KP * M * sizeof(float), 256));  // zeroed by gather_heads_t_kernel
     if (rowmap) {  // ROOT and padding keep label 0
         if (hipMemsetAsync(rels, 0, (size_t)B * L * sizeof(int32_t), st) != hipSuccess ||
             (best_opt && hipMemsetAsync(best_opt, 0, (size_t)B * L * sizeof(float), st) != hipSuccess))
@@ -961,13 +1200,13 @@ static int label_at_heads_fused_run(const void *X1p, const float *x1_inv, const 
     {
         ProfScope ps("gather_heads_t", st);
         hipLaunchKernelGGL(gather_heads_t_kernel, dim3(ceil_div(M, 32), ceil_div(KP, 32)), dim3(1024), 0, st, heads, sentlens,
-                           XF + KP, 2L * KP, M, L, KP, hrow, x2t, rowmap, off);
+                           XF + KP, 2L * KP, M, L, KP, hrow, x2t, rowmap, off, tile_ctr);
         const int rc = check_launch("gather_heads_t_kernel");
         if (rc) return rc;
     }
     // transposed product: rows = the weight image's (relation, head feature) rows, columns = words
     LinearArgs ah{};
-    ah.x2 = x2t; ah.ldx2 = M; ah.P = P; ah.kpc = KPC; ah.kpx = KP; ah.nrel = O;
+    ah.x2 = x2t; ah.ldx2 = M; ah.P = P; ah.kpc = KPC; ah.kpx = KP; ah.nrel = O; ah.tile_ctr = tile_ctr;
     int rc = launch_linear_f16x3("linear:label_stage_a", Wbtcp, 4L * K16, wbtc_inv, X1p, 4L * K16, x1_inv, nullptr, nullptr,
                                  0, O * KPC, M, K16, 0, nullptr, 0, st, nullptr, 0, &ah);
     if (rc) return rc;
