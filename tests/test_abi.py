@@ -109,3 +109,25 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libphonlp_heads.so")
     with pytest.raises(_lib.HeadsLibraryError):
         _lib.lib()
+
+
+def test_fused_label_weight_image_row_order():
+    """HeadWeights._pad_relations: the weight image of phonlp_label_at_heads_fused holds relation o, head feature
+    32*blk + r in row (blk*O + o)*32 + r (include/phonlp_heads.h), rows past KP zero -- host logic, no GPU."""
+    import torch
+    from phonlp_amd import HeadWeights, ops
+    H, O = 40, 5
+    KP, KPC = ops.kp(H), ops.label_kpc(H)
+    assert KPC % 32 == 0 and KPC >= KP
+    g = torch.Generator().manual_seed(0)
+    wbt = torch.randn(O * KP, KP, generator=g)
+    img = HeadWeights._pad_relations(wbt, H, O)
+    assert img.shape == (O * KPC, KP)
+    for o in range(O):
+        for d2 in range(KPC):
+            blk, r = divmod(d2, 32)
+            row = img[(blk * O + o) * 32 + r]
+            if d2 < KP:
+                assert torch.equal(row, wbt[o * KP + d2])
+            else:
+                assert not row.any()
