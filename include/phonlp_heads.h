@@ -408,6 +408,39 @@ int phonlp_dep_loss_grad(const float *arc_logp, const float *raw, const float *T
                          int O, int use_lin, int use_dist, float number_of_words, float *d_arc, float *d_label,
                          float *d_lin, float *d_dist, void *stream);
 
+/* Backward THROUGH the layers (what autograd does behind the reference's modules; the gradients w.r.t. the scores come from
+ * the *_grad entry points above).  All products run on the library's dense-layer kernels (fp32-grade on every engine);
+ * reduction dimensions are zero-padded to multiples of 4 inside the workspace, so the shapes are free; column sums are
+ * taken in a fixed order (no float atomics).
+ *
+ * phonlp_linear_backward: an nn.Linear (+ ReLU) layer Y = act(X W^T + b) -- upos_hid / upos_clf / ner_tag_clf / dep_hid
+ * (annotate_model.py:43-60) and the scorers' W1 / W2 (biaffine.py:73-74, 83): X [M, K] (row pitch ldx), W [N, K], Yact =
+ * the layer's OUTPUT [M, N] (read only when relu: the mask is Yact > 0), dY [M, N]  ->  dX [M, K] = dZ W, dW [N, K] =
+ * dZ^T X, db [N] = column sums of dZ, with dZ = dY * [Yact > 0] (relu) or dY.  Any of dX / dW / db may be NULL. */
+size_t phonlp_linear_backward_ws_bytes(int M, int N, int K);
+int phonlp_linear_backward(const float *X, int ldx, const float *W, int ldw, const float *Yact, int ldy, const float *dY,
+                           int lddy, int M, int N, int K, int relu, float *dX, int lddx, float *dW, int lddw, float *db,
+                           void *ws, size_t ws_bytes, void *stream);
+
+/* phonlp_bilinear_backward: a ONE-output PairwiseBilinear (biaffine.py:21-37, O = 1: the unlabeled, linearization and
+ * distance scorers), S[b,i,j] = sum X1'[b,i,d1] Wbt[d2][d1] X2'[b,j,d2] with XF = (X1' | X2') [B*L, 2*KP] the scorer's
+ * post-ReLU features incl. the ones column (as phonlp_label_project / the arc path produce them) and Wbt the
+ * phonlp_pack_bilinear image [KP, KP].  Given G = dL/dS [B, L, L]:  dXF [B*L, 2*KP] = (dX1' | dX2') (columns >= H: the
+ * ones / padding columns, to be ignored), dWbt [KP, KP] in the Wbt layout (dweight[d1][d2] of the reference's
+ * (H+1) x (H+1) x 1 parameter = dWbt[d2][d1]).  The label scorer: phonlp_label_backward below. */
+size_t phonlp_bilinear_backward_ws_bytes(int B, int L, int H);
+int phonlp_bilinear_backward(const float *XF, const float *Wbt, const float *G, int B, int L, int H, float *dXF,
+                             float *dWbt, void *ws, size_t ws_bytes, void *stream);
+
+/* phonlp_label_backward: the label scorer (O relations), whose loss reads the scores at the GOLD heads only
+ * (jointmodel/model.py:218-223): g [B, L, O] = dL/d deprel_scores[b, i, gold_head[b,i], :] as phonlp_dep_loss_grad's
+ * d_label gives it (zero on ROOT / padding rows), XF [B*L, 2*KP] and Wbt [O*KP, KP] as for phonlp_label_project.
+ * dXF [B*L, 2*KP] = (dX1' | dX2') (dX2' summed over the dependents of each head, ascending), dWbt [O*KP, KP].  L <= 1024. */
+size_t phonlp_label_backward_ws_bytes(int B, int L, int H, int O);
+int phonlp_label_backward(const float *XF, const float *Wbt, const float *g, const int32_t *gold_head,
+                          const int32_t *sentlens, int B, int L, int H, int O, float *dXF, float *dWbt, void *ws,
+                          size_t ws_bytes, void *stream);
+
 /* POS training loss, forward value -- models/jointmodel/model.py:128-135 (pos_forward with use_soft_pos=False; crit_pos
  * :94 = CrossEntropyLoss(ignore_index=1), mean reduction), dropout the identity:
  *   loss[0] = mean over the words i < sentlens[b] with gold_upos != ignore_index of

@@ -360,6 +360,77 @@ def dep_loss_grad(arc_logp: Tensor, raw: Optional[Tensor], T: Tensor, XF: Tensor
     return d_arc, d_label, d_lin, d_dist
 
 
+def linear_backward(X: Tensor, W: Tensor, Yact: Optional[Tensor], dY: Tensor, relu: bool, need_dX: bool = True,
+                    need_dW: bool = True, need_db: bool = True):
+    """Backward of Y = act(X W^T + b) (an nn.Linear, optionally followed by ReLU): X [M,K], W [N,K], Yact = the layer's
+    output [M,N] (only read when relu), dY [M,N] -> (dX [M,K], dW [N,K], db [N]), None where not asked for."""
+    _need(X, torch.float32, "X")
+    _need(W, torch.float32, "W")
+    _need(dY, torch.float32, "dY")
+    if X.dim() != 2 or W.dim() != 2 or dY.dim() != 2 or X.shape[1] != W.shape[1] or tuple(dY.shape) != (X.shape[0], W.shape[0]):
+        raise ValueError("linear_backward: X [M,K], W [N,K], dY [M,N] expected")
+    if relu:
+        if Yact is None or tuple(Yact.shape) != tuple(dY.shape):
+            raise ValueError("linear_backward: relu needs the layer's output Yact [M,N]")
+        _need(Yact, torch.float32, "Yact")
+    M, K = X.shape
+    N = W.shape[0]
+    dev = X.device
+    dX = torch.empty((M, K), dtype=torch.float32, device=dev) if need_dX else None
+    dW = torch.empty((N, K), dtype=torch.float32, device=dev) if need_dW else None
+    db = torch.empty((N,), dtype=torch.float32, device=dev) if need_db else None
+    nb = lib().phonlp_linear_backward_ws_bytes(M, N, K)
+    ws = torch.empty((nb,), dtype=torch.uint8, device=dev)
+    check(lib().phonlp_linear_backward(_p(X), K, _p(W), K, _p(Yact) if relu else None, N, _p(dY), N, M, N, K, int(relu),
+                                       _p(dX), K, _p(dW), K, _p(db), _p(ws), nb, _stream()), "phonlp_linear_backward")
+    return dX, dW, db
+
+
+def bilinear_backward(XF: Tensor, Wbt: Tensor, G: Tensor, H: int) -> Tuple[Tensor, Tensor]:
+    """Backward of a one-output bilinear scorer S[b,i,j] = X1'[b,i] Wb X2'[b,j] given G = dL/dS [B,L,L]: XF [B*L, 2*KP]
+    the scorer's post-ReLU features, Wbt [KP, KP] the packed weight -> (dXF [B*L, 2*KP], dWbt [KP, KP])."""
+    _need(XF, torch.float32, "XF")
+    _need(Wbt, torch.float32, "Wbt")
+    _need(G, torch.float32, "G")
+    KP = kp(H)
+    if G.dim() != 3 or G.shape[1] != G.shape[2]:
+        raise ValueError("bilinear_backward: G must be [B, L, L]")
+    B, L = G.shape[0], G.shape[1]
+    if tuple(XF.shape) != (B * L, 2 * KP) or tuple(Wbt.shape) != (KP, KP):
+        raise ValueError("bilinear_backward: XF [B*L, 2*KP] and Wbt [KP, KP] expected")
+    dev = XF.device
+    dXF = torch.empty((B * L, 2 * KP), dtype=torch.float32, device=dev)
+    dWbt = torch.empty((KP, KP), dtype=torch.float32, device=dev)
+    nb = lib().phonlp_bilinear_backward_ws_bytes(B, L, H)
+    ws = torch.empty((nb,), dtype=torch.uint8, device=dev)
+    check(lib().phonlp_bilinear_backward(_p(XF), _p(Wbt), _p(G), B, L, H, _p(dXF), _p(dWbt), _p(ws), nb, _stream()),
+          "phonlp_bilinear_backward")
+    return dXF, dWbt
+
+
+def label_backward(XF: Tensor, Wbt: Tensor, g: Tensor, gold_head: Tensor, sentlens: Tensor, H: int,
+                   O: int) -> Tuple[Tensor, Tensor]:
+    """Backward of the label scorer's scores at the gold heads: g [B,L,O] (dep_loss_grad's d_label), XF [B*L, 2*KP], Wbt
+    [O*KP, KP] -> (dXF [B*L, 2*KP], dWbt [O*KP, KP])."""
+    _need(XF, torch.float32, "XF")
+    _need(Wbt, torch.float32, "Wbt")
+    _need(g, torch.float32, "g")
+    _need(gold_head, torch.int32, "gold_head")
+    _need(sentlens, torch.int32, "sentlens")
+    KP = kp(H)
+    B, L = gold_head.shape
+    if tuple(g.shape) != (B, L, O) or tuple(XF.shape) != (B * L, 2 * KP) or tuple(Wbt.shape) != (O * KP, KP) or sentlens.numel() != B:
+        raise ValueError("label_backward: g [B,L,O], gold_head [B,L], XF [B*L, 2*KP], Wbt [O*KP, KP], sentlens [B] expected")
+    dev = XF.device
+    dXF = torch.empty((B * L, 2 * KP), dtype=torch.float32, device=dev)
+    dWbt = torch.empty((O * KP, KP), dtype=torch.float32, device=dev)
+    nb = lib().phonlp_label_backward_ws_bytes(B, L, H, O)
+    ws = torch.empty((nb,), dtype=torch.uint8, device=dev)
+    check(lib().phonlp_label_backward(_p(XF), _p(Wbt), _p(g), _p(gold_head), _p(sentlens), B, L, H, O, _p(dXF), _p(dWbt),
+                                      _p(ws), nb, _stream()), "phonlp_label_backward")
+    return dXF, dWbt
+
+
 @dep_loss.register_fake
 def _(arc_logp, raw, T, XF, gold_head, gold_rel, sentlens, H, O, use_lin, use_dist, number_of_words):
     return arc_logp.new_empty((5,))

@@ -79,6 +79,65 @@ def gen_biaffine():
     save("biaffine.npz", **arrs)
 
 
+# ---------------------------------------------------------------------------- f4: backward through a scorer
+def gen_biaffine_backward():
+    """The reference's own autograd through DeepBiaffineScorer (O = 1: the unlabeled / linearization / distance scorers,
+    biaffine.py:69-85) under a random upstream gradient G: loss = sum(G * scores).  Records the inputs and the gradients
+    of the input and of every parameter the forward touches (W_bilin.bias is never added: no gradient)."""
+    g = torch.Generator().manual_seed(4242)
+    arrs = {}
+    cases = [(3, 10, 20, 12), (2, 7, 24, 16), (4, 33, 36, 24)]  # L not a multiple of 4: the padded reductions
+    for c, (B, L, D, H) in enumerate(cases):
+        m = bia.DeepBiaffineScorer(D, D, H, 1, pairwise=True, dropout=0.5).eval()
+        with torch.no_grad():
+            m.scorer.W_bilin.weight.copy_(torch.randn(H + 1, H + 1, 1, generator=g) * 0.3)
+        h = torch.randn(B, L, D, generator=g).requires_grad_(True)
+        G = torch.randn(B, L, L, generator=g)
+        out = m(h, h)  # [B, L, L, 1]
+        (out.squeeze(3) * G).sum().backward()
+        arrs[f"c{c}_h"] = h.detach().numpy()
+        arrs[f"c{c}_G"] = G.numpy()
+        arrs[f"c{c}_out"] = out.detach().squeeze(3).contiguous().numpy()
+        for k, v in m.state_dict().items():
+            arrs[f"c{c}_p_{k}"] = v.numpy()
+        arrs[f"c{c}_d_h"] = h.grad.numpy()
+        for k, v in m.named_parameters():
+            if v.grad is not None:
+                arrs[f"c{c}_d_{k}"] = v.grad.numpy()
+        assert m.scorer.W_bilin.bias.grad is None
+    arrs["n_cases"] = np.int64(len(cases))
+    # the label scorer: O relations, the loss reads the scores at the gold heads only (jointmodel/model.py:218-223);
+    # g = 0 on ROOT and padding rows, as the parser loss leaves them
+    lcases = [(3, 10, 20, 12, 5), (2, 13, 24, 16, 7)]
+    for c, (B, L, D, H, O) in enumerate(lcases):
+        m = bia.DeepBiaffineScorer(D, D, H, O, pairwise=True, dropout=0.5).eval()
+        with torch.no_grad():
+            m.scorer.W_bilin.weight.copy_(torch.randn(H + 1, H + 1, O, generator=g) * 0.3)
+        h = torch.randn(B, L, D, generator=g).requires_grad_(True)
+        lens = torch.randint(3, L + 1, (B,), generator=g)
+        lens[0] = L
+        head = torch.stack([torch.randint(0, int(n), (L,), generator=g) for n in lens])
+        gl = torch.randn(B, L, O, generator=g)
+        live = (torch.arange(L)[None, :] < lens[:, None]) & (torch.arange(L)[None, :] >= 1)
+        gl = gl * live[:, :, None]
+        out = m(h, h)  # [B, L, L, O]
+        at_head = torch.gather(out, 2, head.view(B, L, 1, 1).expand(-1, -1, -1, O)).squeeze(2)  # [B, L, O]
+        (at_head * gl).sum().backward()
+        arrs[f"l{c}_h"] = h.detach().numpy()
+        arrs[f"l{c}_g"] = gl.numpy()
+        arrs[f"l{c}_head"] = head.numpy().astype(np.int32)
+        arrs[f"l{c}_lens"] = lens.numpy().astype(np.int32)
+        arrs[f"l{c}_at_head"] = at_head.detach().numpy()
+        for k, v in m.state_dict().items():
+            arrs[f"l{c}_p_{k}"] = v.numpy()
+        arrs[f"l{c}_d_h"] = h.grad.numpy()
+        for k, v in m.named_parameters():
+            if v.grad is not None:
+                arrs[f"l{c}_d_{k}"] = v.grad.numpy()
+    arrs["n_label_cases"] = np.int64(len(lcases))
+    save("biaffine_backward.npz", **arrs)
+
+
 # ---------------------------------------------------------------------------- F3 viterbi
 def gen_viterbi():
     rng = np.random.default_rng(303)
@@ -707,6 +766,9 @@ if __name__ == "__main__":
     if "--only-dep-loss-grad" in sys.argv:
         gen_dep_loss_grad()
         sys.exit(0)
+    if "--only-biaffine-backward" in sys.argv:
+        gen_biaffine_backward()
+        sys.exit(0)
     torch.set_num_threads(4)
     gen_biaffine()
     gen_viterbi()
@@ -718,4 +780,5 @@ if __name__ == "__main__":
     gen_trainer()
     gen_dep_loss()
     gen_dep_loss_grad()
+    gen_biaffine_backward()
     gen_config1()
