@@ -284,6 +284,74 @@ class TaskHeads:
             w.linearization and w.n_arc_scorers > 1, w.distance and w.n_arc_scorers > 1, nw)
         return {"d_unlabeled": d_arc, "d_label": d_label, "d_lin": d_lin, "d_dist": d_dist}
 
+    # ---- ... and on through the scorers and dep_hid: what loss.backward() leaves in the parameters' .grad
+    def parser_backward(self, enc: torch.Tensor, sentlens, gold_head, gold_rel, number_of_words=None):
+        """Backward of the parser loss (ref jointmodel/model.py:162-236, model in .eval()) through the four scorers and
+        dep_hid -> {"grads": {reference parameter name: gradient in the reference's shape} for `unlabeled` / `deprel` /
+        `linearization` / `distance` (.W1 / .W2 .weight, .bias, .scorer.W_bilin.weight) and `dep_hid`, "d_hidden": the
+        gradient w.r.t. dep_hid's output [B,L,D], "d_feat": w.r.t. its input [B,L,D] (= [enc ; pos_emb]; padded rows
+        zero: the reference's padding is a constant)}.  Un-folded weights (the folds are an inference-time rewrite)."""
+        w = self.w
+        n = w.n_arc_scorers
+        dep = self.parser(enc, sentlens, want_raw=n > 1, want_label_argmax=False)
+        lens, hidden, feat = dep["sentlens"], dep["hidden_out"], dep["feat"]
+        B, L, D = hidden.shape
+        M, H, O, KP = B * L, w.H, w.O, ops.kp(w.H)
+
+        def with_root(t):
+            t = torch.as_tensor(t).to(device=enc.device, dtype=torch.int32)
+            if t.shape[1] == L - 1:
+                t = torch.nn.functional.pad(t, (1, 0))
+            return t.contiguous()
+
+        gh, gr = with_root(gold_head), with_root(gold_rel)
+        XF, T = ops.label_project(hidden, w.lab_W12, w.lab_b12, w.lab_Wbt, H, O)
+        nw = float(lens.sum().item()) if number_of_words is None else float(number_of_words)
+        use_lin, use_dist = w.linearization and n > 1, w.distance and n > 1
+        d_arc, d_label, d_lin, d_dist = ops.dep_loss_grad(dep["arc_logp"], dep.get("raw"), T, XF, gh, gr, lens, H, O,
+                                                          use_lin, use_dist, nw)
+        hm = hidden.reshape(M, D)
+        # the one-output scorers: the unlabeled one gets the dense arc gradient, the other two theirs at the gold head
+        at_head = lambda v: torch.zeros((B, L, L), dtype=torch.float32, device=enc.device).scatter_(
+            2, gh.long().unsqueeze(2), v.unsqueeze(2))
+        Gs = [d_arc] + ([at_head(d_lin) if use_lin else None, at_head(d_dist) if use_dist else None] if n > 1 else [])
+        XFa = ops.linear(hm, w.arc_W12, w.arc_b12, True, None, 0)  # [M, n * 2KP]: (X1' | X2') per scorer
+        dXFa = torch.zeros_like(XFa)
+        grads = {}
+
+        def unpack_bilinear(dWbt, Ox):  # [Ox*KP, KP] -> the reference's (H+1, H+1, Ox) parameter (flat (d1, o, d2): biaffine.py:27-35)
+            return dWbt.view(Ox, KP, KP)[:, :H + 1, :H + 1].permute(2, 0, 1).contiguous().view(H + 1, H + 1, Ox)
+
+        def first_layers(name, dW12, db12, row0):
+            grads[f"{name}.W1.weight"], grads[f"{name}.W1.bias"] = dW12[row0:row0 + H], db12[row0:row0 + H]
+            grads[f"{name}.W2.weight"], grads[f"{name}.W2.bias"] = dW12[row0 + KP:row0 + KP + H], db12[row0 + KP:row0 + KP + H]
+
+        for s_, (name, G) in enumerate(zip(SCORERS, Gs)):
+            if G is None:
+                continue
+            c0 = s_ * 2 * KP
+            dXF_s, dWbt_s = ops.bilinear_backward(XFa[:, c0:c0 + 2 * KP].contiguous(),
+                                                  w.arc_Wbt[s_ * KP:(s_ + 1) * KP].contiguous(), G.contiguous(), H)
+            dXFa[:, c0:c0 + 2 * KP] = dXF_s
+            grads[f"{name}.scorer.W_bilin.weight"] = unpack_bilinear(dWbt_s, 1)
+        dh_arc, dW12a, db12a = ops.linear_backward(hm, w.arc_W12, XFa, dXFa, True)
+        for s_, (name, G) in enumerate(zip(SCORERS, Gs)):
+            if G is not None:
+                first_layers(name, dW12a, db12a, s_ * 2 * KP)
+        # the label scorer: its loss reads the scores at the gold heads
+        dXFl, dWbtl = ops.label_backward(XF, w.lab_Wbt, d_label, gh, lens, H, O)
+        grads["deprel.scorer.W_bilin.weight"] = unpack_bilinear(dWbtl, O)
+        dh_lab, dW12l, db12l = ops.linear_backward(hm, w.lab_W12, XF, dXFl, True)
+        first_layers("deprel", dW12l, db12l, 0)
+        d_hidden = (dh_arc + dh_lab).view(B, L, D)
+        # dep_hid (no activation): only the live rows reach it -- the padded rows of its output are the zeros of
+        # pad_packed_sequence, constants of the graph (jointmodel/model.py:182-185)
+        live = (torch.arange(L, device=enc.device)[None, :] < lens[:, None]).unsqueeze(2)
+        d_live = (d_hidden * live).reshape(M, D).contiguous()
+        d_feat, dWd, dbd = ops.linear_backward(feat.reshape(M, D).contiguous(), w.dep_hid_w, None, d_live, False)
+        grads["dep_hid.weight"], grads["dep_hid.bias"] = dWd, dbd
+        return {"grads": grads, "d_hidden": d_hidden, "d_feat": d_feat.view(B, L, D)}
+
     # ---- training model's pos_forward(use_soft_pos=False) after the gather, loss value only (ref jointmodel/model.py:128-135)
     def pos_loss(self, enc: torch.Tensor, sentlens, gold_upos, ignore_index=1) -> torch.Tensor:
         """-> fp32 [3] on the device: mean cross-entropy (what the reference returns as `loss`), sum, words counted."""

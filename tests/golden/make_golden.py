@@ -657,6 +657,10 @@ def gen_dep_loss_grad():
         arrs[f"c{c}_d_label"] = d_dep_h.numpy()
         arrs[f"c{c}_d_lin"] = at(d_lin).numpy()
         arrs[f"c{c}_d_dist"] = at(d_dst).numpy()
+        # ... and what the same backward left in the parameters of the four scorers and of dep_hid
+        for pname, prm in model.named_parameters():
+            if prm.grad is not None and pname.split(".")[0] in ("unlabeled", "deprel", "linearization", "distance", "dep_hid"):
+                arrs[f"c{c}_dp_{pname}"] = prm.grad.detach().numpy().copy()
         print(f"dep loss grad case {c}: B={B} L={L} loss={loss.item():.6f} |d_unl|={d_unl.abs().sum():.4f} "
               f"|d_label|={d_dep_h.abs().sum():.4f} |d_lin|={at(d_lin).abs().sum():.4f} |d_dist|={at(d_dst).abs().sum():.4f}")
     arrs["n_cases"] = np.int64(len(cases))

@@ -65,6 +65,31 @@ def _gold_trees(lens1, L, O_, seed):
     return head, rel
 
 
+def test_parser_backward_reference_fixture(dev, engine, golden):
+    """TaskHeads.parser_backward: the gradients the reference's loss.backward() left in the parameters of the four
+    scorers and of dep_hid (dep_loss_grad_small.npz, the same backward call as above), through phonlp_bilinear_backward /
+    phonlp_label_backward / phonlp_linear_backward.  2e-4 of each gradient's largest entry."""
+    from phonlp_amd import HeadWeights, TaskHeads
+    z = golden("dep_loss_grad_small.npz")
+    heads = TaskHeads(HeadWeights.from_state_dict(_params(z), dev))
+    names = [k[len("c0_dp_"):] for k in z.files if k.startswith("c0_dp_")]
+    assert len(names) == 22
+    for c in range(int(z["n_cases"])):
+        lens = z[f"c{c}_lens"].tolist()
+        out = heads.parser_backward(torch.from_numpy(z[f"c{c}_enc"]).to(dev), lens, torch.from_numpy(z[f"c{c}_head"]),
+                                    torch.from_numpy(z[f"c{c}_rel"]), int(z[f"c{c}_nwords"]))
+        for name in names:
+            want = torch.from_numpy(z[f"c{c}_dp_{name}"])
+            got = out["grads"][name].cpu()
+            assert got.shape == want.shape, (name, got.shape, want.shape)
+            scale = float(want.abs().max()) + 1e-12
+            err = float((got - want).abs().max())
+            assert err <= 2e-4 * scale, f"case {c} {name}: max error {err:.3e} against scale {scale:.3e}"
+        L = max(lens)
+        live = torch.arange(L)[None, :] < torch.tensor(lens)[:, None]
+        assert not out["d_feat"].cpu()[~live].any()
+
+
 @pytest.mark.parametrize("B,L,ragged,lin,dist", [(8, 64, True, True, True), (6, 128, False, True, True),
                                                  (5, 40, True, False, True), (5, 40, True, True, False),
                                                  (4, 33, True, False, False), (2, 200, True, True, True)])
