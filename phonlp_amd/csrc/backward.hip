@@ -53,13 +53,13 @@ __global__ __launch_bounds__(256) void bw_mask_kernel(const float *dY, long lddy
     }
 }
 
-// part[g][n] = sum of dZ[m][n] over the rows m of group g (1024 rows, ascending); then db[n] = sum_g part[g][n], ascending
+// part[g][n] = sum of dZ[m][n] over the rows m of group g (128 rows, ascending); then db[n] = sum_g part[g][n], ascending
 __global__ __launch_bounds__(256) void bw_colsum_part_kernel(const float *dZ, long ld, int M, int N, float *part) {
     const int n = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
     if (n >= N) return;
-    const int m1 = min(M, (g + 1) * 1024);
+    const int m1 = min(M, (g + 1) * 128);
     float s = 0.f;
-    for (int m = g * 1024; m < m1; ++m) s += dZ[(long)m * ld + n];
+    for (int m = g * 128; m < m1; ++m) s += dZ[(long)m * ld + n];
     part[(long)g * N + n] = s;
 }
 __global__ __launch_bounds__(256) void bw_colsum_final_kernel(const float *part, int G, int N, float *db) {
@@ -128,6 +128,47 @@ static int transpose(const float *X, long ldx, int rows, int cols, float *Y, lon
 }
 
 static inline int up4(int v) { return (v + 3) & ~3; }
+
+// A product whose output is small and whose reduction is the batch (dW = dZ^T X, dWb = U^T X1: a few dozen output tiles
+// over K = B*L) would leave most CUs idle: the reduction is cut into S chunks run as ONE batched product into S partial
+// outputs, which are then added in ascending order (fixed: no float atomics).  Kc: chunk length (multiple of 4); the
+// operands' rows are zero-padded to S*Kc.
+struct SplitK {
+    int S, Kc;
+    long kpad() const { return (long)S * Kc; }
+};
+static SplitK plan_splitk(int Mo, int No, int K) {
+    const int tiles = ceil_div(Mo, 256) * ceil_div(No, 128);
+    int S = 512 / tiles;
+    if (S > K / 256) S = K / 256;
+    if (S > 64) S = 64;
+    if (S < 1) S = 1;
+    SplitK p;
+    p.S = S;
+    p.Kc = up4(ceil_div(K, S));
+    return p;
+}
+__global__ __launch_bounds__(256) void bw_sum_parts_kernel(const float *part, long stride, int S, long total, int No, float *Y,
+                                                           long ldy) {
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        for (int k = 0; k < S; ++k) v += part[k * stride + idx];
+        const long m = idx / No;
+        Y[m * ldy + (idx - m * No)] = v;
+    }
+}
+static int gemm_splitk(const char *tag, const float *A, const float *Bm, float *Y, long ldy, int Mo, int No, SplitK sk,
+                       float *part, hipStream_t st) {
+    const long ld = sk.kpad();
+    if (sk.S == 1)
+        return launch_linear(tag, A, ld, Bm, ld, nullptr, Y, ldy, Mo, No, sk.Kc, 0, nullptr, 0, st, nullptr, 1, 0, 0, 0);
+    int rc = launch_linear(tag, A, ld, Bm, ld, nullptr, part, No, Mo, No, sk.Kc, 0, nullptr, 0, st, nullptr, sk.S, sk.Kc, sk.Kc,
+                           (long)Mo * No);
+    if (rc) return rc;
+    ProfScope ps("bw_sum_parts", st);
+    hipLaunchKernelGGL(bw_sum_parts_kernel, dim3(1024), dim3(256), 0, st, part, (long)Mo * No, sk.S, (long)Mo * No, No, Y, ldy);
+    return check_launch("bw_sum_parts_kernel");
+}
 static inline float *carve(char *&p, size_t floats) {
     float *r = (float *)p;
     p += align_up(floats * sizeof(float), 256);
@@ -140,9 +181,10 @@ using namespace phonlp;
 
 extern "C" size_t phonlp_linear_backward_ws_bytes(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
-    const size_t M4 = up4(M), N4 = up4(N);
+    const size_t M4 = (size_t)plan_splitk(N, K, M).kpad(), N4 = up4(N);
     return align_up((size_t)M * N4 * 4, 256) + align_up((size_t)N * M4 * 4, 256) + align_up((size_t)K * M4 * 4, 256) +
-           align_up((size_t)K * N4 * 4, 256) + align_up((size_t)ceil_div(M, 1024) * N * 4, 256);
+           align_up((size_t)K * N4 * 4, 256) + align_up((size_t)ceil_div(M, 128) * N * 4, 256) +
+           align_up((size_t)plan_splitk(N, K, M).S * N * K * 4, 256);  // + the split product's partial outputs
 }
 
 extern "C" int phonlp_linear_backward(const float *X, int ldx, const float *W, int ldw, const float *Yact, int ldy,
@@ -154,10 +196,12 @@ extern "C" int phonlp_linear_backward(const float *X, int ldx, const float *W, i
     if (!ws || ws_bytes < phonlp_linear_backward_ws_bytes(M, N, K))
         return fail(PHONLP_ERR_WORKSPACE, "linear_backward: workspace too small");
     hipStream_t st = as_stream(stream);
-    const int M4 = up4(M), N4 = up4(N), G = ceil_div(M, 1024);
+    const int N4 = up4(N), G = ceil_div(M, 128);
+    const SplitK sk = plan_splitk(N, K, M);
+    const long M4 = sk.kpad();  // the padded reduction length of dW = dZ^T X
     char *p = (char *)ws;
     float *dZ = carve(p, (size_t)M * N4), *dZT = carve(p, (size_t)N * M4), *XT = carve(p, (size_t)K * M4);
-    float *WT = carve(p, (size_t)K * N4), *part = carve(p, (size_t)G * N);
+    float *WT = carve(p, (size_t)K * N4), *part = carve(p, (size_t)G * N), *parts = carve(p, (size_t)sk.S * N * K);
     {
         ProfScope ps("bw_mask", st);
         hipLaunchKernelGGL(bw_mask_kernel, dim3(2048), dim3(256), 0, st, dY, (long)lddy, Yact, (long)ldy, M, N, N4, relu, dZ);
@@ -177,18 +221,20 @@ extern "C" int phonlp_linear_backward(const float *X, int ldx, const float *W, i
             return rc;
     }
     if (dW) {  // dW[n][k] = sum_m dZT[n][m] XT[k][m]
-        if ((rc = transpose(dZ, N4, M, N, dZT, M4, M4, 1, 0, 0, st))) return rc;
-        if ((rc = transpose(X, ldx, M, K, XT, M4, M4, 1, 0, 0, st))) return rc;
-        if ((rc = launch_linear("bw:dW", dZT, M4, XT, M4, nullptr, dW, lddw, N, K, M4, 0, nullptr, 0, st, nullptr, 1, 0, 0, 0)))
-            return rc;
+        if ((rc = transpose(dZ, N4, M, N, dZT, M4, (int)M4, 1, 0, 0, st))) return rc;
+        if ((rc = transpose(X, ldx, M, K, XT, M4, (int)M4, 1, 0, 0, st))) return rc;
+        if ((rc = gemm_splitk("bw:dW", dZT, XT, dW, lddw, N, K, sk, parts, st))) return rc;
     }
     return PHONLP_OK;
 }
 
 extern "C" size_t phonlp_bilinear_backward_ws_bytes(int B, int L, int H) {
     if (B <= 0 || L <= 0 || H <= 0) return 0;
-    const size_t KP = kp_of(H), M = (size_t)B * L, M4 = up4((int)M), L4 = up4(L);
-    return 2 * align_up(KP * M4 * 4, 256) +              // X1T, UT
+    const size_t KP = kp_of(H), M = (size_t)B * L, L4 = up4(L);
+    const SplitK sk = plan_splitk((int)KP, (int)KP, (int)M);
+    const size_t M4 = (size_t)sk.kpad();
+    return align_up((size_t)sk.S * KP * KP * 4, 256) +   // partial outputs of dWb
+           2 * align_up(KP * M4 * 4, 256) +              // X1T, UT
            2 * align_up(M * KP * 4, 256) +               // T, U
            2 * align_up((size_t)B * L * L4 * 4, 256) +   // G, G^T with the reduction dimension padded
            align_up(KP * KP * 4, 256) +                  // Wb^T
@@ -207,8 +253,11 @@ extern "C" int phonlp_bilinear_backward(const float *XF, const float *Wbt, const
     if (!ws || ws_bytes < phonlp_bilinear_backward_ws_bytes(B, L, H))
         return fail(PHONLP_ERR_WORKSPACE, "bilinear_backward: workspace too small");
     hipStream_t st = as_stream(stream);
-    const int KP = kp_of(H), M = B * L, M4 = up4(M), L4 = up4(L);
+    const int KP = kp_of(H), M = B * L, L4 = up4(L);
+    const SplitK sk = plan_splitk(KP, KP, M);
+    const long M4 = sk.kpad();
     char *p = (char *)ws;
+    float *parts = carve(p, (size_t)sk.S * KP * KP);
     float *X1T = carve(p, (size_t)KP * M4), *UT = carve(p, (size_t)KP * M4);
     float *T = carve(p, (size_t)M * KP), *U = carve(p, (size_t)M * KP);
     float *Gp = carve(p, (size_t)B * L * L4), *GTp = carve(p, (size_t)B * L * L4);
@@ -237,9 +286,9 @@ extern "C" int phonlp_bilinear_backward(const float *XF, const float *Wbt, const
                             (long)L * L4, (long)KP * L4, (long)L * 2 * KP)))
         return rc;
     // dWb[d2][d1] = sum_m UT[d2][m] X1T[d1][m]
-    if ((rc = transpose(U, KP, M, KP, UT, M4, M4, 1, 0, 0, st))) return rc;
-    if ((rc = transpose(XF, 2L * KP, M, KP, X1T, M4, M4, 1, 0, 0, st))) return rc;
-    return launch_linear("bw:dWb", UT, M4, X1T, M4, nullptr, dWbt, KP, KP, KP, M4, 0, nullptr, 0, st, nullptr, 1, 0, 0, 0);
+    if ((rc = transpose(U, KP, M, KP, UT, M4, (int)M4, 1, 0, 0, st))) return rc;
+    if ((rc = transpose(XF, 2L * KP, M, KP, X1T, M4, (int)M4, 1, 0, 0, st))) return rc;
+    return gemm_splitk("bw:dWb", UT, X1T, dWbt, KP, KP, KP, sk, parts, st);
 }
 
 extern "C" size_t phonlp_label_backward_ws_bytes(int B, int L, int H, int O) {

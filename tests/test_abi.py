@@ -96,6 +96,21 @@ def test_argument_errors_without_gpu(heads_lib):
     assert b"dep_loss_grad" in heads_lib.phonlp_last_error()
     assert heads_lib.phonlp_dep_loss_grad(one, one, one, one, one, one, one, 1, 2, 400, 33, 1, 1, 0.0, one, one, one, one,
                                           None) == -1
+    # backward through the layers: NULL operands, pitches shorter than the rows, ReLU without the layer's output,
+    # workspaces too small, a misaligned operand
+    assert heads_lib.phonlp_linear_backward(None, 8, one, 8, None, 4, one, 4, 2, 4, 8, 0, one, 8, one, 8, one, one, 1 << 30, None) == -1
+    assert b"linear_backward" in heads_lib.phonlp_last_error()
+    assert heads_lib.phonlp_linear_backward(one, 4, one, 8, None, 4, one, 4, 2, 4, 8, 0, one, 8, one, 8, one, one, 1 << 30, None) == -1
+    assert heads_lib.phonlp_linear_backward(one, 8, one, 8, None, 4, one, 4, 2, 4, 8, 1, one, 8, one, 8, one, one, 1 << 30, None) == -1
+    assert heads_lib.phonlp_linear_backward(one, 8, one, 8, None, 4, one, 4, 2, 4, 8, 0, one, 8, one, 8, one, one, 16, None) == -2
+    assert heads_lib.phonlp_linear_backward_ws_bytes(0, 4, 8) == 0 and heads_lib.phonlp_linear_backward_ws_bytes(32768, 2448, 868) > 0
+    assert heads_lib.phonlp_bilinear_backward(one, one, None, 2, 8, 400, one, one, one, 1 << 30, None) == -1
+    assert heads_lib.phonlp_bilinear_backward(one, one, one, 2, 8, 400, one, one, one, 16, None) == -2
+    assert heads_lib.phonlp_bilinear_backward(ctypes.c_void_p(one.value + 4), one, one, 2, 8, 400, one, one, one, 1 << 30, None) == -1
+    assert heads_lib.phonlp_label_backward(one, one, one, None, one, 2, 8, 400, 33, one, one, one, 1 << 30, None) == -1
+    assert heads_lib.phonlp_label_backward(one, one, one, one, one, 2, 2000, 400, 33, one, one, one, 1 << 40, None) == -1  # L > 1024
+    assert heads_lib.phonlp_label_backward(one, one, one, one, one, 2, 8, 400, 33, one, one, one, 16, None) == -2
+    assert b"label_backward" in heads_lib.phonlp_last_error()
     assert heads_lib.phonlp_crf_nll_grad_static_max_bytes() == 4 << 20
     assert heads_lib.phonlp_crf_nll_grad_static(one, one, None, None, one, 4096, 4, 64, 1.0, one, one, None) == -4  # B*T*T*4 > 4 MiB
     assert heads_lib.phonlp_get_mst_fast_path() in (0, 1)

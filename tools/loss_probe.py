@@ -53,3 +53,17 @@ with KernelTimer() as kt:
     torch.cuda.synchronize()
 for k, (n, mean, mn) in sorted(kt.stats.items()):
     print(f"  {k}: {n} launches, mean {mean * 1e3:.1f} us, min {mn * 1e3:.1f} us")
+# the backward through the scorers and dep_hid (TaskHeads.parser_backward) and its per-kernel split
+enc_h = enc_dep.to(dev)
+lens_l = [L] * B
+t_bw = timed(lambda: heads.parser_backward(enc_h, lens_l, head, rel, B * L), n=5)
+t_fw = timed(lambda: heads.parser(enc_h, lens_l, want_raw=True, want_label_argmax=False), n=5)
+print(f"parser_backward {t_bw:.2f} ms (of which its own forward {t_fw:.2f} ms) at B={B} L={L}")
+with KernelTimer(max_samples=4096) as kt:
+    heads.parser_backward(enc_h, lens_l, head, rel, B * L)
+    torch.cuda.synchronize()
+tot = {}
+for k, (n, mean, mn) in sorted(kt.stats.items()):
+    if k.startswith("bw"):
+        tot[k] = n * mean
+print("  backward kernels (ms per call):", {k: round(v, 3) for k, v in sorted(tot.items(), key=lambda kv: -kv[1])})
