@@ -359,6 +359,26 @@ class TaskHeads:
         gold = torch.as_tensor(gold_upos).to(device=enc.device, dtype=torch.int32).contiguous()
         return ops.pos_loss(tag["upos_logits"].contiguous(), gold, tag["sentlens"], ignore_index)
 
+    # ---- ... and its backward through upos_clf and upos_hid (what loss.backward() leaves behind pos_forward)
+    def pos_backward(self, enc: torch.Tensor, sentlens, gold_upos, ignore_index=1):
+        """-> {"loss": fp32 [3] as pos_loss, "grads": {"upos_hid.weight", "upos_hid.bias", "upos_clf.weight",
+        "upos_clf.bias"}, "d_enc": the gradient w.r.t. the gathered encoder rows [B,L,E] (zero on padding)}."""
+        w = self.w
+        lens = as_sentlens(sentlens, enc.device)
+        B, L, E = enc.shape
+        M = B * L
+        x = enc.reshape(M, E).contiguous()
+        hid = ops.linear(x, w.upos_hid_w, w.upos_hid_b, True, None, 0)            # relu(upos_hid(x))
+        logits = ops.linear(hid, w.upos_clf_w, w.upos_clf_b, False, None, 0).view(B, L, -1)
+        gold = torch.as_tensor(gold_upos).to(device=enc.device, dtype=torch.int32).contiguous()
+        loss = ops.pos_loss(logits, gold, lens, ignore_index)
+        d_logits = ops.pos_loss_grad(logits, gold, lens, loss, ignore_index)       # zero on padding / ignored words
+        U = logits.shape[2]
+        d_hid, dWc, dbc = ops.linear_backward(hid, w.upos_clf_w, None, d_logits.reshape(M, U).contiguous(), False)
+        d_x, dWh, dbh = ops.linear_backward(x, w.upos_hid_w, hid, d_hid, True)
+        return {"loss": loss, "d_enc": d_x.view(B, L, E),
+                "grads": {"upos_hid.weight": dWh, "upos_hid.bias": dbh, "upos_clf.weight": dWc, "upos_clf.bias": dbc}}
+
     # ---- decoders
     def viterbi(self, ner_logits: torch.Tensor, sentlens):
         lens = as_sentlens(sentlens, ner_logits.device)

@@ -667,6 +667,58 @@ def gen_dep_loss_grad():
     save("dep_loss_grad_small.npz", **arrs)
 
 
+# ---------------------------------------------------------------------------- F9c backward of the POS loss
+def gen_pos_backward():
+    """The training model's pos_forward(use_soft_pos=False) (models/jointmodel/model.py:107-135) in .eval() mode, then
+    loss.backward(): the .grad of upos_hid / upos_clf and the gradient w.r.t. the gathered encoder rows."""
+    import tempfile
+    amodel = build_joint_model(seed=1010)
+    from phonlp.models.jointmodel.trainer import JointTrainer
+    with tempfile.TemporaryDirectory() as td:
+        amodel.phobert.save_pretrained(td)
+        args = dict(amodel.args, pretrained_lm=td)
+        trainer = JointTrainer(args=args, vocab=amodel.vocab, config_phobert=amodel.phobert.config, use_cuda=False)
+    missing, unexpected = trainer.model.load_state_dict(amodel.state_dict(), strict=False)
+    assert not unexpected and all(m.startswith("drop_replacement") for m in missing), (missing, unexpected)
+    model = trainer.model.eval()
+    with open(os.path.join(REF, "sample_data", "input.txt")) as f:
+        lines = [ln.strip() for ln in f if ln.strip()]
+    arrs = {f"p_{k}": v for k, v in head_state(amodel).items()}
+    captured = []
+    orig = model.phobert.forward
+
+    def spy(*a, **kw):  # the encoder's last layer, kept in the graph: its .grad is the gradient w.r.t. the encoder rows
+        out = orig(*a, **kw)
+        out[2][-1].retain_grad()
+        captured.append(out)
+        return out
+
+    model.phobert.forward = spy
+    g = torch.Generator().manual_seed(13)
+    cases = [lines[20:31] + ["x", "y z w"], lines[90:93], ["p q"]]
+    for c, text in enumerate(cases):
+        sents = [ln.split(" ") for ln in text]
+        data_t = amodel.chunk_batches(amodel.process_data_tagger(batch_text=sents), len(sents))
+        tok_t, fsw_t, _, _, _, lens_t = amodel.get_batch(0, data_t)
+        upos = torch.randint(0, len(amodel.vocab["upos"]), (len(lens_t), max(lens_t)), generator=g)
+        model.zero_grad()
+        ploss, _ = model.pos_forward(tok_t, fsw_t, lens_t, use_soft_pos=False, upos=upos)
+        ploss.backward()
+        last = captured[-1][2][-1]
+        B = len(lens_t)
+        arrs[f"c{c}_enc"] = torch.stack([last[i].detach().index_select(0, fsw_t[i]) for i in range(B)]).numpy()
+        arrs[f"c{c}_d_enc"] = torch.stack([last.grad[i].index_select(0, fsw_t[i]) for i in range(B)]).numpy()
+        arrs[f"c{c}_lens"] = np.asarray(lens_t, dtype=np.int64)
+        arrs[f"c{c}_upos"] = upos.numpy()
+        arrs[f"c{c}_loss"] = np.float32(ploss.item())
+        for pname in ("upos_hid.weight", "upos_hid.bias", "upos_clf.weight", "upos_clf.bias"):
+            mod, attr = pname.split(".")
+            arrs[f"c{c}_dp_{pname}"] = getattr(getattr(model, mod), attr).grad.detach().numpy().copy()
+        print(f"pos backward case {c}: B={B} loss={ploss.item():.6f}")
+    arrs["n_cases"] = np.int64(len(cases))
+    save("pos_backward_small.npz", **arrs)
+
+
 # ---------------------------------------------------------------------------- F10 BASELINE config 1 at full head sizes
 def gen_config1():
     """BASELINE config 1: the reference's annotate() (annotate_model.py:218-339) over all 100 sentences of
@@ -770,6 +822,9 @@ if __name__ == "__main__":
     if "--only-dep-loss-grad" in sys.argv:
         gen_dep_loss_grad()
         sys.exit(0)
+    if "--only-pos-backward" in sys.argv:
+        gen_pos_backward()
+        sys.exit(0)
     if "--only-biaffine-backward" in sys.argv:
         gen_biaffine_backward()
         sys.exit(0)
@@ -785,4 +840,5 @@ if __name__ == "__main__":
     gen_dep_loss()
     gen_dep_loss_grad()
     gen_biaffine_backward()
+    gen_pos_backward()
     gen_config1()

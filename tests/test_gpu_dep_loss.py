@@ -65,6 +65,26 @@ def _gold_trees(lens1, L, O_, seed):
     return head, rel
 
 
+def test_pos_backward_reference_fixture(dev, engine, golden):
+    """TaskHeads.pos_backward against the reference's pos_forward(use_soft_pos=False) + loss.backward()
+    (pos_backward_small.npz): the loss, the .grad of upos_hid / upos_clf, the gradient w.r.t. the encoder rows."""
+    from phonlp_amd import HeadWeights, TaskHeads
+    z = golden("pos_backward_small.npz")
+    heads = TaskHeads(HeadWeights.from_state_dict(_params(z), dev))
+    for c in range(int(z["n_cases"])):
+        lens = z[f"c{c}_lens"].tolist()
+        out = heads.pos_backward(torch.from_numpy(z[f"c{c}_enc"]).to(dev), lens, torch.from_numpy(z[f"c{c}_upos"]))
+        assert abs(float(out["loss"][0]) - float(z[f"c{c}_loss"])) <= 1e-5 * abs(float(z[f"c{c}_loss"]))
+        pairs = [(out["grads"][k], z[f"c{c}_dp_{k}"], k) for k in ("upos_hid.weight", "upos_hid.bias", "upos_clf.weight",
+                                                                 "upos_clf.bias")]
+        pairs.append((out["d_enc"], z[f"c{c}_d_enc"], "d_enc"))
+        for got, want, name in pairs:
+            want = torch.from_numpy(want)
+            scale = float(want.abs().max()) + 1e-12
+            err = float((got.cpu() - want).abs().max())
+            assert err <= 2e-4 * scale, f"case {c} {name}: max error {err:.3e} against scale {scale:.3e}"
+
+
 def test_parser_backward_reference_fixture(dev, engine, golden):
     """TaskHeads.parser_backward: the gradients the reference's loss.backward() left in the parameters of the four
     scorers and of dep_hid (dep_loss_grad_small.npz, the same backward call as above), through phonlp_bilinear_backward /
