@@ -441,6 +441,11 @@ int phonlp_label_backward(const float *XF, const float *Wbt, const float *g, con
                           const int32_t *sentlens, int B, int L, int H, int O, float *dXF, float *dWbt, void *ws,
                           size_t ws_bytes, void *stream);
 
+/* The soft POS distribution pos_dis = softmax(upos logits) that feeds the tag embedding of the NER and parser heads
+ * (jointmodel/model.py:135,150,171), rows of [M, U] (U <= 1024), and its backward dZ = P * (dP - sum_u P dP). */
+int phonlp_softmax_rows(const float *Z, int M, int U, float *P, void *stream);
+int phonlp_softmax_rows_backward(const float *P, const float *dP, int M, int U, float *dZ, void *stream);
+
 /* POS training loss, forward value -- models/jointmodel/model.py:128-135 (pos_forward with use_soft_pos=False; crit_pos
  * :94 = CrossEntropyLoss(ignore_index=1), mean reduction), dropout the identity:
  *   loss[0] = mean over the words i < sentlens[b] with gold_upos != ignore_index of

@@ -119,6 +119,34 @@ __global__ __launch_bounds__(256) void bw_label_scatter_kernel(const float *dX2h
     }
 }
 
+// Row soft-max (the soft POS distribution, ref jointmodel/model.py:135 / annotate_model.py:140,177) and its backward
+// dZ = P * (dP - sum_u P dP): one wavefront per row, U <= 1024.
+__global__ __launch_bounds__(256) void bw_softmax_fwd_kernel(const float *Z, int M, int U, float *P) {
+    const int lane = threadIdx.x & 63;
+    const long m = blockIdx.x * 4L + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const float *z = Z + m * U;
+    float mx = -INFINITY;
+    for (int u = lane; u < U; u += 64) mx = fmaxf(mx, z[u]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+    for (int u = lane; u < U; u += 64) sum += expf(z[u] - mx);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    for (int u = lane; u < U; u += 64) P[m * U + u] = expf(z[u] - mx) / sum;
+}
+__global__ __launch_bounds__(256) void bw_softmax_bwd_kernel(const float *P, const float *dP, int M, int U, float *dZ) {
+    const int lane = threadIdx.x & 63;
+    const long m = blockIdx.x * 4L + (threadIdx.x >> 6);
+    if (m >= M) return;
+    float dot = 0.f;
+    for (int u = lane; u < U; u += 64) dot += P[m * U + u] * dP[m * U + u];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+    for (int u = lane; u < U; u += 64) dZ[m * U + u] = P[m * U + u] * (dP[m * U + u] - dot);
+}
+
 static int transpose(const float *X, long ldx, int rows, int cols, float *Y, long ldy, int rows_pad, int nbatch, long bsx,
                      long bsy, hipStream_t st) {
     ProfScope ps("bw_transpose", st);
@@ -341,4 +369,20 @@ extern "C" int phonlp_label_backward(const float *XF, const float *Wbt, const fl
     if ((rc = transpose(Z, OK, M, OK, ZT, M4, M4, 1, 0, 0, st))) return rc;
     if ((rc = transpose(XF, 2L * KP, M, KP, X1T, M4, M4, 1, 0, 0, st))) return rc;
     return launch_linear("bw:label_dWbt", ZT, M4, X1T, M4, nullptr, dWbt, KP, OK, KP, M4, 0, nullptr, 0, st, nullptr, 1, 0, 0, 0);
+}
+
+/* Row soft-max P = softmax(Z) over the last dimension ([M, U], U <= 1024) and its backward dZ = P * (dP - sum_u P dP):
+ * the soft POS distribution that feeds the tag embedding of the NER and parser heads (jointmodel/model.py:135,150,171). */
+extern "C" int phonlp_softmax_rows(const float *Z, int M, int U, float *P, void *stream) {
+    if (!Z || !P || M <= 0 || U <= 0 || U > 1024) return fail(PHONLP_ERR_SHAPE, "softmax_rows: bad argument (U <= 1024)");
+    ProfScope ps("bw_softmax", as_stream(stream));
+    hipLaunchKernelGGL(bw_softmax_fwd_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, as_stream(stream), Z, M, U, P);
+    return check_launch("bw_softmax_fwd_kernel");
+}
+extern "C" int phonlp_softmax_rows_backward(const float *P, const float *dP, int M, int U, float *dZ, void *stream) {
+    if (!P || !dP || !dZ || M <= 0 || U <= 0 || U > 1024)
+        return fail(PHONLP_ERR_SHAPE, "softmax_rows_backward: bad argument (U <= 1024)");
+    ProfScope ps("bw_softmax", as_stream(stream));
+    hipLaunchKernelGGL(bw_softmax_bwd_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, as_stream(stream), P, dP, M, U, dZ);
+    return check_launch("bw_softmax_bwd_kernel");
 }

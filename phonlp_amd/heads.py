@@ -288,9 +288,10 @@ class TaskHeads:
     def parser_backward(self, enc: torch.Tensor, sentlens, gold_head, gold_rel, number_of_words=None):
         """Backward of the parser loss (ref jointmodel/model.py:162-236, model in .eval()) through the four scorers and
         dep_hid -> {"grads": {reference parameter name: gradient in the reference's shape} for `unlabeled` / `deprel` /
-        `linearization` / `distance` (.W1 / .W2 .weight, .bias, .scorer.W_bilin.weight) and `dep_hid`, "d_hidden": the
-        gradient w.r.t. dep_hid's output [B,L,D], "d_feat": w.r.t. its input [B,L,D] (= [enc ; pos_emb]; padded rows
-        zero: the reference's padding is a constant)}.  Un-folded weights (the folds are an inference-time rewrite)."""
+        `linearization` / `distance` (.W1 / .W2 .weight, .bias, .scorer.W_bilin.weight), `dep_hid`, `upos_emb_matrix_dep`,
+        `upos_hid`, `upos_clf`; "d_hidden": the gradient w.r.t. dep_hid's output [B,L,D]; "d_feat": w.r.t. its input
+        [B,L,D] (= [enc ; pos_emb]; padded rows zero: the reference's padding is a constant); "d_enc": w.r.t. the
+        gathered encoder rows [B,L,E], both routes added}.  Un-folded weights (the folds are an inference-time rewrite)."""
         w = self.w
         n = w.n_arc_scorers
         dep = self.parser(enc, sentlens, want_raw=n > 1, want_label_argmax=False)
@@ -350,7 +351,14 @@ class TaskHeads:
         d_live = (d_hidden * live).reshape(M, D).contiguous()
         d_feat, dWd, dbd = ops.linear_backward(feat.reshape(M, D).contiguous(), w.dep_hid_w, None, d_live, False)
         grads["dep_hid.weight"], grads["dep_hid.bias"] = dWd, dbd
-        return {"grads": grads, "d_hidden": d_hidden, "d_feat": d_feat.view(B, L, D)}
+        # [enc ; pos_emb]: the embedding half runs on through the soft POS distribution into the POS layers
+        E = enc.shape[2]
+        d_x, d_emb, g_pos = self._soft_pos_backward(enc.reshape(M, E).contiguous(), dep["upos_logits"].reshape(M, -1),
+                                                    w.emb_dep, d_feat[:, E:])
+        grads["upos_emb_matrix_dep"] = d_emb
+        grads.update(g_pos)
+        return {"grads": grads, "d_hidden": d_hidden, "d_feat": d_feat.view(B, L, D),
+                "d_enc": (d_feat[:, :E] + d_x).view(B, L, E)}
 
     # ---- training model's pos_forward(use_soft_pos=False) after the gather, loss value only (ref jointmodel/model.py:128-135)
     def pos_loss(self, enc: torch.Tensor, sentlens, gold_upos, ignore_index=1) -> torch.Tensor:
@@ -358,6 +366,43 @@ class TaskHeads:
         tag = self.tagger(enc, sentlens)
         gold = torch.as_tensor(gold_upos).to(device=enc.device, dtype=torch.int32).contiguous()
         return ops.pos_loss(tag["upos_logits"].contiguous(), gold, tag["sentlens"], ignore_index)
+
+    # ---- the soft POS embedding's backward, shared by the NER and parser heads: pos_emb = softmax(upos_clf(relu(
+    # upos_hid(x)))) @ emb (ref jointmodel/model.py:128-135 with use_soft_pos=True, :150-151 / :171-172)
+    def _soft_pos_backward(self, x: torch.Tensor, upos_logits: torch.Tensor, emb: torch.Tensor, d_pos_emb: torch.Tensor):
+        """x [M,E] encoder rows, upos_logits [M,U] of those rows, emb [U,TE], d_pos_emb [M,TE] (zero on padded rows) ->
+        (d_x [M,E], d_emb [U,TE], {upos_hid / upos_clf gradients})."""
+        w = self.w
+        hid = ops.linear(x, w.upos_hid_w, w.upos_hid_b, True, None, 0)
+        P = ops.softmax_rows(upos_logits.contiguous())
+        # pos_emb = P @ emb = P (emb^T)^T: a bias-free linear layer with weight emb^T [TE, U]
+        d_P, d_embT, _ = ops.linear_backward(P, emb.t().contiguous(), None, d_pos_emb.contiguous(), False, need_db=False)
+        d_logits = ops.softmax_rows_backward(P, d_P)
+        d_hid, dWc, dbc = ops.linear_backward(hid, w.upos_clf_w, None, d_logits, False)
+        d_x, dWh, dbh = ops.linear_backward(x, w.upos_hid_w, hid, d_hid, True)
+        return d_x, d_embT.t().contiguous(), {"upos_hid.weight": dWh, "upos_hid.bias": dbh, "upos_clf.weight": dWc,
+                                              "upos_clf.bias": dbc}
+
+    # ---- the NER loss's backward (ref jointmodel/model.py:139-160 + crf.py:24-46 under loss.backward(), model in .eval())
+    def ner_backward(self, enc: torch.Tensor, sentlens, gold_tags):
+        """-> {"grads": {"ner_tag_clf.weight", "ner_tag_clf.bias", "crit_ner._transitions", "upos_emb_matrix_ner",
+        "upos_hid.*", "upos_clf.*"}, "d_enc": the gradient w.r.t. the gathered encoder rows [B,L,E]}: CRF NLL averaged
+        over the batch -> ReLU -> ner_tag_clf -> [enc ; soft POS embedding] -> the POS layers."""
+        w = self.w
+        tag = self.tagger(enc, sentlens)
+        lens, feat, logits = tag["sentlens"], tag["feat"], tag["ner_logits"]
+        B, L, E = enc.shape
+        M, D = B * L, feat.shape[2]
+        gold = torch.as_tensor(gold_tags).to(device=enc.device, dtype=torch.int32).contiguous()
+        d_logits, d_trans = ops.crf_nll_grad(logits.contiguous(), w.trans, None, lens, gold, 1.0 / B)
+        T = logits.shape[2]
+        d_feat, dWn, dbn = ops.linear_backward(feat.reshape(M, D).contiguous(), w.ner_w, logits.reshape(M, T).contiguous(),
+                                               d_logits.reshape(M, T).contiguous(), True)
+        d_x, d_emb, g_pos = self._soft_pos_backward(enc.reshape(M, E).contiguous(), tag["upos_logits"].reshape(M, -1),
+                                                    w.emb_ner, d_feat[:, E:])
+        grads = {"ner_tag_clf.weight": dWn, "ner_tag_clf.bias": dbn, "crit_ner._transitions": d_trans,
+                 "upos_emb_matrix_ner": d_emb, **g_pos}
+        return {"grads": grads, "d_enc": (d_feat[:, :E] + d_x).view(B, L, E)}
 
     # ---- ... and its backward through upos_clf and upos_hid (what loss.backward() leaves behind pos_forward)
     def pos_backward(self, enc: torch.Tensor, sentlens, gold_upos, ignore_index=1):

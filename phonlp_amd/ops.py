@@ -408,6 +408,27 @@ def bilinear_backward(XF: Tensor, Wbt: Tensor, G: Tensor, H: int) -> Tuple[Tenso
     return dXF, dWbt
 
 
+def softmax_rows(Z: Tensor) -> Tensor:
+    """softmax over the last dimension of a [M, U] device tensor (the soft POS distribution)."""
+    _need(Z, torch.float32, "Z")
+    M, U = Z.shape
+    P = torch.empty_like(Z)
+    check(lib().phonlp_softmax_rows(_p(Z), M, U, _p(P), _stream()), "phonlp_softmax_rows")
+    return P
+
+
+def softmax_rows_backward(P: Tensor, dP: Tensor) -> Tensor:
+    """dZ = P * (dP - sum_u P dP) for P = softmax_rows(Z)."""
+    _need(P, torch.float32, "P")
+    _need(dP, torch.float32, "dP")
+    if P.shape != dP.shape or P.dim() != 2:
+        raise ValueError("softmax_rows_backward: P, dP [M, U] expected")
+    dZ = torch.empty_like(P)
+    check(lib().phonlp_softmax_rows_backward(_p(P), _p(dP), P.shape[0], P.shape[1], _p(dZ), _stream()),
+          "phonlp_softmax_rows_backward")
+    return dZ
+
+
 def label_backward(XF: Tensor, Wbt: Tensor, g: Tensor, gold_head: Tensor, sentlens: Tensor, H: int,
                    O: int) -> Tuple[Tensor, Tensor]:
     """Backward of the label scorer's scores at the gold heads: g [B,L,O] (dep_loss_grad's d_label), XF [B*L, 2*KP], Wbt

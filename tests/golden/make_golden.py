@@ -597,7 +597,13 @@ def gen_dep_loss_grad():
     arrs = {f"p_{k}": v for k, v in head_state(amodel).items()}
     captured = []
     orig = model.phobert.forward
-    model.phobert.forward = lambda *a, **kw: (captured.append(orig(*a, **kw)), captured[-1])[1]
+    def spy(*a, **kw):  # the encoder's last layer stays in the graph: its .grad is the gradient w.r.t. the encoder rows
+        out = orig(*a, **kw)
+        out[2][-1].retain_grad()
+        captured.append(out)
+        return out
+
+    model.phobert.forward = spy
     grads = {}
 
     def keep(name):
@@ -649,6 +655,7 @@ def gen_dep_loss_grad():
             assert not z.any()
         assert not d_unl[:, 0].any()
         arrs[f"c{c}_enc"] = torch.stack([enc[i].index_select(0, fsw[i]) for i in range(B)]).numpy()
+        arrs[f"c{c}_d_enc"] = torch.stack([captured[-1][2][-1].grad[i].index_select(0, fsw[i]) for i in range(B)]).numpy()
         arrs[f"c{c}_lens"] = np.asarray(lens, dtype=np.int64)
         arrs[f"c{c}_head"], arrs[f"c{c}_rel"] = head.numpy(), rel.numpy()
         arrs[f"c{c}_nwords"] = np.int64(nwords)
@@ -659,7 +666,8 @@ def gen_dep_loss_grad():
         arrs[f"c{c}_d_dist"] = at(d_dst).numpy()
         # ... and what the same backward left in the parameters of the four scorers and of dep_hid
         for pname, prm in model.named_parameters():
-            if prm.grad is not None and pname.split(".")[0] in ("unlabeled", "deprel", "linearization", "distance", "dep_hid"):
+            if prm.grad is not None and pname.split(".")[0] in ("unlabeled", "deprel", "linearization", "distance", "dep_hid",
+                                                                "upos_emb_matrix_dep", "upos_hid", "upos_clf"):
                 arrs[f"c{c}_dp_{pname}"] = prm.grad.detach().numpy().copy()
         print(f"dep loss grad case {c}: B={B} L={L} loss={loss.item():.6f} |d_unl|={d_unl.abs().sum():.4f} "
               f"|d_label|={d_dep_h.abs().sum():.4f} |d_lin|={at(d_lin).abs().sum():.4f} |d_dist|={at(d_dst).abs().sum():.4f}")
@@ -717,6 +725,63 @@ def gen_pos_backward():
         print(f"pos backward case {c}: B={B} loss={ploss.item():.6f}")
     arrs["n_cases"] = np.int64(len(cases))
     save("pos_backward_small.npz", **arrs)
+
+
+# ---------------------------------------------------------------------------- F9d backward of the NER loss
+def gen_ner_backward():
+    """The training model's ner_forward (models/jointmodel/model.py:139-160: soft POS embedding -> ner_tag_clf -> ReLU ->
+    CRFLoss) in .eval() mode, then loss.backward(): the .grad of every parameter it reaches and the gradient w.r.t. the
+    gathered encoder rows."""
+    import tempfile
+    amodel = build_joint_model(seed=1111)
+    from phonlp.models.jointmodel.trainer import JointTrainer
+    with tempfile.TemporaryDirectory() as td:
+        amodel.phobert.save_pretrained(td)
+        args = dict(amodel.args, pretrained_lm=td)
+        trainer = JointTrainer(args=args, vocab=amodel.vocab, config_phobert=amodel.phobert.config, use_cuda=False)
+    missing, unexpected = trainer.model.load_state_dict(amodel.state_dict(), strict=False)
+    assert not unexpected and all(m.startswith("drop_replacement") for m in missing), (missing, unexpected)
+    model = trainer.model.eval()
+    with torch.no_grad():  # the reference starts the transitions at zero (crf.py:21): make them count
+        model.crit_ner._transitions.copy_(torch.randn(model.crit_ner._transitions.shape, generator=torch.Generator().manual_seed(5)) * 0.3)
+    with open(os.path.join(REF, "sample_data", "input.txt")) as f:
+        lines = [ln.strip() for ln in f if ln.strip()]
+    arrs = {f"p_{k}": v for k, v in head_state(model).items()}
+    captured = []
+    orig = model.phobert.forward
+
+    def spy(*a, **kw):
+        out = orig(*a, **kw)
+        out[2][-1].retain_grad()
+        captured.append(out)
+        return out
+
+    model.phobert.forward = spy
+    g = torch.Generator().manual_seed(14)
+    cases = [lines[30:41] + ["x", "y z w"], lines[50:53], ["p q"]]
+    names = ("ner_tag_clf.weight", "ner_tag_clf.bias", "crit_ner._transitions", "upos_emb_matrix_ner", "upos_hid.weight",
+             "upos_hid.bias", "upos_clf.weight", "upos_clf.bias")
+    params = dict(model.named_parameters())
+    for c, text in enumerate(cases):
+        sents = [ln.split(" ") for ln in text]
+        data_t = amodel.chunk_batches(amodel.process_data_tagger(batch_text=sents), len(sents))
+        tok_t, fsw_t, wmask_t, _, _, lens_t = amodel.get_batch(0, data_t)
+        B, L = len(lens_t), max(lens_t)
+        tags = torch.randint(0, len(amodel.vocab["ner_tag"]), (B, L), generator=g)
+        model.zero_grad()
+        loss, logits = model.ner_forward(tok_t, fsw_t, wmask_t, lens_t, tags)
+        loss.backward()
+        last = captured[-1][2][-1]
+        arrs[f"c{c}_enc"] = torch.stack([last[i].detach().index_select(0, fsw_t[i]) for i in range(B)]).numpy()
+        arrs[f"c{c}_d_enc"] = torch.stack([last.grad[i].index_select(0, fsw_t[i]) for i in range(B)]).numpy()
+        arrs[f"c{c}_lens"] = np.asarray(lens_t, dtype=np.int64)
+        arrs[f"c{c}_tags"] = tags.numpy()
+        arrs[f"c{c}_loss"] = np.float32(loss.item())
+        for pname in names:
+            arrs[f"c{c}_dp_{pname}"] = params[pname].grad.detach().numpy().copy()
+        print(f"ner backward case {c}: B={B} L={L} loss={loss.item():.6f}")
+    arrs["n_cases"] = np.int64(len(cases))
+    save("ner_backward_small.npz", **arrs)
 
 
 # ---------------------------------------------------------------------------- F10 BASELINE config 1 at full head sizes
@@ -822,6 +887,9 @@ if __name__ == "__main__":
     if "--only-dep-loss-grad" in sys.argv:
         gen_dep_loss_grad()
         sys.exit(0)
+    if "--only-ner-backward" in sys.argv:
+        gen_ner_backward()
+        sys.exit(0)
     if "--only-pos-backward" in sys.argv:
         gen_pos_backward()
         sys.exit(0)
@@ -841,4 +909,5 @@ if __name__ == "__main__":
     gen_dep_loss_grad()
     gen_biaffine_backward()
     gen_pos_backward()
+    gen_ner_backward()
     gen_config1()

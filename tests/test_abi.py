@@ -111,6 +111,8 @@ def test_argument_errors_without_gpu(heads_lib):
     assert heads_lib.phonlp_label_backward(one, one, one, one, one, 2, 2000, 400, 33, one, one, one, 1 << 40, None) == -1  # L > 1024
     assert heads_lib.phonlp_label_backward(one, one, one, one, one, 2, 8, 400, 33, one, one, one, 16, None) == -2
     assert b"label_backward" in heads_lib.phonlp_last_error()
+    assert heads_lib.phonlp_softmax_rows(None, 4, 24, one, None) == -1 and heads_lib.phonlp_softmax_rows(one, 4, 2000, one, None) == -1
+    assert heads_lib.phonlp_softmax_rows_backward(one, None, 4, 24, one, None) == -1
     assert heads_lib.phonlp_crf_nll_grad_static_max_bytes() == 4 << 20
     assert heads_lib.phonlp_crf_nll_grad_static(one, one, None, None, one, 4096, 4, 64, 1.0, one, one, None) == -4  # B*T*T*4 > 4 MiB
     assert heads_lib.phonlp_get_mst_fast_path() in (0, 1)

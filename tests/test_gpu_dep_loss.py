@@ -93,7 +93,7 @@ def test_parser_backward_reference_fixture(dev, engine, golden):
     z = golden("dep_loss_grad_small.npz")
     heads = TaskHeads(HeadWeights.from_state_dict(_params(z), dev))
     names = [k[len("c0_dp_"):] for k in z.files if k.startswith("c0_dp_")]
-    assert len(names) == 22
+    assert len(names) == 27  # 4 scorers x 5, dep_hid x 2, the tag embedding, upos_hid / upos_clf x 2
     for c in range(int(z["n_cases"])):
         lens = z[f"c{c}_lens"].tolist()
         out = heads.parser_backward(torch.from_numpy(z[f"c{c}_enc"]).to(dev), lens, torch.from_numpy(z[f"c{c}_head"]),
@@ -108,6 +108,29 @@ def test_parser_backward_reference_fixture(dev, engine, golden):
         L = max(lens)
         live = torch.arange(L)[None, :] < torch.tensor(lens)[:, None]
         assert not out["d_feat"].cpu()[~live].any()
+        want = torch.from_numpy(z[f"c{c}_d_enc"])  # the encoder's last layer at the words' first sub-words
+        err = float((out["d_enc"].cpu() - want).abs().max())
+        assert err <= 2e-4 * float(want.abs().max()), f"case {c} d_enc: max error {err:.3e}"
+
+
+def test_ner_backward_reference_fixture(dev, engine, golden):
+    """TaskHeads.ner_backward against the reference's ner_forward + loss.backward() (ner_backward_small.npz): CRF NLL ->
+    ReLU -> ner_tag_clf -> [enc ; soft POS embedding] -> the POS layers; every parameter's .grad and the encoder rows'."""
+    from phonlp_amd import HeadWeights, TaskHeads
+    z = golden("ner_backward_small.npz")
+    heads = TaskHeads(HeadWeights.from_state_dict(_params(z), dev))
+    names = [k[len("c0_dp_"):] for k in z.files if k.startswith("c0_dp_")]
+    assert len(names) == 8
+    for c in range(int(z["n_cases"])):
+        lens = z[f"c{c}_lens"].tolist()
+        out = heads.ner_backward(torch.from_numpy(z[f"c{c}_enc"]).to(dev), lens, torch.from_numpy(z[f"c{c}_tags"]))
+        pairs = [(out["grads"][k], z[f"c{c}_dp_{k}"], k) for k in names] + [(out["d_enc"], z[f"c{c}_d_enc"], "d_enc")]
+        for got, want, name in pairs:
+            want = torch.from_numpy(want)
+            assert got.shape == want.shape, (name, got.shape, want.shape)
+            scale = float(want.abs().max()) + 1e-12
+            err = float((got.cpu() - want).abs().max())
+            assert err <= 2e-4 * scale, f"case {c} {name}: max error {err:.3e} against scale {scale:.3e}"
 
 
 @pytest.mark.parametrize("B,L,ragged,lin,dist", [(8, 64, True, True, True), (6, 128, False, True, True),
