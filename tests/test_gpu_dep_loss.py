@@ -113,6 +113,40 @@ def test_parser_backward_reference_fixture(dev, engine, golden):
         assert err <= 2e-4 * float(want.abs().max()), f"case {c} d_enc: max error {err:.3e}"
 
 
+@pytest.mark.parametrize("lin,dist", [(True, True), (False, True), (True, False), (False, False)])
+def test_parser_backward_vs_oracle_autograd(dev, lin, dist):
+    """The same at the real head sizes (E=768, H=400, O=33) and with the linearization / distance scorers switched off
+    (args of the reference, annotate_model.py:77-94): torch autograd through the oracle's dep_heads + dep_loss (pinned
+    to the reference by the fixtures above) gives the gradients of every parameter the loss reaches."""
+    from phonlp_amd import HeadWeights, TaskHeads
+    from phonlp_amd import synthetic as S
+    B, L = 4, 24
+    sd = S.make_state_dict()
+    enc_dep, _ = S.make_encoder_outputs(B, L, seed=77)
+    lens1 = [24, 17, 9, 3]
+    head, rel = _gold_trees(lens1, L, 33, seed=5)
+    nw = sum(lens1)
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    enc_leaf = enc_dep.clone().requires_grad_(True)
+    dep = O.dep_heads(enc_leaf, lens1, p, linearization=lin, distance=dist)
+    total, _ = O.dep_loss(dep, lens1, head[:, 1:].numpy(), rel[:, 1:].numpy(), nw, linearization=lin, distance=dist)
+    total.backward()
+    heads = TaskHeads(HeadWeights.from_state_dict(sd, dev, linearization=lin, distance=dist))
+    out = heads.parser_backward(enc_dep.to(dev), lens1, head, rel, nw)
+    scorers = ["unlabeled", "deprel"] + (["linearization"] if lin else []) + (["distance"] if dist else [])
+    names = [f"{s_}.{k}" for s_ in scorers for k in ("W1.weight", "W1.bias", "W2.weight", "W2.bias", "scorer.W_bilin.weight")]
+    names += ["dep_hid.weight", "dep_hid.bias", "upos_emb_matrix_dep", "upos_hid.weight", "upos_hid.bias", "upos_clf.weight",
+              "upos_clf.bias"]
+    assert sorted(out["grads"]) == sorted(names)
+    for name in names:
+        want = p[name].grad
+        scale = float(want.abs().max()) + 1e-12
+        err = float((out["grads"][name].cpu() - want).abs().max())
+        assert err <= 3e-4 * scale, f"{name}: max error {err:.3e} against scale {scale:.3e}"
+    err = float((out["d_enc"].cpu() - enc_leaf.grad).abs().max())
+    assert err <= 3e-4 * float(enc_leaf.grad.abs().max())
+
+
 def test_ner_backward_reference_fixture(dev, engine, golden):
     """TaskHeads.ner_backward against the reference's ner_forward + loss.backward() (ner_backward_small.npz): CRF NLL ->
     ReLU -> ner_tag_clf -> [enc ; soft POS embedding] -> the POS layers; every parameter's .grad and the encoder rows'."""
