@@ -434,10 +434,11 @@ int phonlp_bilinear_backward(const float *XF, const float *Wbt, const float *G, 
 
 /* phonlp_label_backward: the label scorer (O relations), whose loss reads the scores at the GOLD heads only
  * (jointmodel/model.py:218-223): g [B, L, O] = dL/d deprel_scores[b, i, gold_head[b,i], :] as phonlp_dep_loss_grad's
- * d_label gives it (zero on ROOT / padding rows), XF [B*L, 2*KP] and Wbt [O*KP, KP] as for phonlp_label_project.
+ * d_label gives it (zero on ROOT / padding rows), XF [B*L, 2*KP] and Wbt [O*KP, KP] as for phonlp_label_project, T_opt
+ * = phonlp_label_project's T [B*L, O*KP] when the caller kept it (NULL: recomputed).
  * dXF [B*L, 2*KP] = (dX1' | dX2') (dX2' summed over the dependents of each head, ascending), dWbt [O*KP, KP].  L <= 1024. */
 size_t phonlp_label_backward_ws_bytes(int B, int L, int H, int O);
-int phonlp_label_backward(const float *XF, const float *Wbt, const float *g, const int32_t *gold_head,
+int phonlp_label_backward(const float *XF, const float *Wbt, const float *T_opt, const float *g, const int32_t *gold_head,
                           const int32_t *sentlens, int B, int L, int H, int O, float *dXF, float *dWbt, void *ws,
                           size_t ws_bytes, void *stream);
 

@@ -71,7 +71,7 @@ SIGNATURES = {
     "phonlp_bilinear_backward_ws_bytes": (_z, [_i, _i, _i]),
     "phonlp_bilinear_backward": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _p, _z, _p]),
     "phonlp_label_backward_ws_bytes": (_z, [_i, _i, _i, _i]),
-    "phonlp_label_backward": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _z, _p]),
+    "phonlp_label_backward": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _z, _p]),
     "phonlp_softmax_rows": (_i, [_p, _i, _i, _p, _p]),
     "phonlp_softmax_rows_backward": (_i, [_p, _p, _i, _i, _p, _p]),
     "phonlp_dep_loss_grad": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, ctypes.c_float, _p, _p, _p, _p, _p]),

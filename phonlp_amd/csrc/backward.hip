@@ -331,10 +331,11 @@ extern "C" size_t phonlp_label_backward_ws_bytes(int B, int L, int H, int O) {
 
 /* The label scorer (O relations; ref biaffine.py:21-37, jointmodel/model.py:218-223), backward of the scores AT THE GOLD
  * HEADS: g [B, L, O] = dL/d deprel_scores[b, i, gold_head[b,i], :] (phonlp_dep_loss_grad's d_label: zero on ROOT and
- * padding rows), XF / Wbt as phonlp_label_project takes and makes them.  dXF [B*L, 2*KP] = (dX1' | dX2'), dWbt [O*KP, KP]. */
-extern "C" int phonlp_label_backward(const float *XF, const float *Wbt, const float *g, const int32_t *gold_head,
-                                     const int32_t *sentlens, int B, int L, int H, int O, float *dXF, float *dWbt, void *ws,
-                                     size_t ws_bytes, void *stream) {
+ * padding rows), XF / Wbt as phonlp_label_project takes and makes them, T_opt = that call's T [B*L, O*KP] or NULL
+ * (recomputed).  dXF [B*L, 2*KP] = (dX1' | dX2'), dWbt [O*KP, KP]. */
+extern "C" int phonlp_label_backward(const float *XF, const float *Wbt, const float *T_opt, const float *g,
+                                     const int32_t *gold_head, const int32_t *sentlens, int B, int L, int H, int O,
+                                     float *dXF, float *dWbt, void *ws, size_t ws_bytes, void *stream) {
     if (!XF || !Wbt || !g || !gold_head || !sentlens || !dXF || !dWbt || B <= 0 || L <= 0 || L > 1024 || H <= 0 || O <= 0)
         return fail(PHONLP_ERR_SHAPE, "label_backward: bad argument (L <= 1024)");
     if (((uintptr_t)XF & 15) || ((uintptr_t)Wbt & 15) || ((uintptr_t)dXF & 15))
@@ -356,12 +357,14 @@ extern "C" int phonlp_label_backward(const float *XF, const float *Wbt, const fl
     if ((rc = transpose(Wbt, KP, OK, KP, WbtT, OK, OK, 1, 0, 0, st))) return rc;
     if ((rc = launch_linear("bw:label_dX1", Z, OK, WbtT, OK, nullptr, dXF, 2L * KP, M, KP, OK, 0, nullptr, 0, st, nullptr, 1, 0, 0, 0)))
         return rc;
-    // T = X1 Wbt^T (the forward's stage A), then dX2 at the heads and its scatter to the heads' rows
-    if ((rc = launch_linear("bw:label_T", XF, 2L * KP, Wbt, KP, nullptr, T, OK, M, OK, KP, 0, nullptr, 0, st, nullptr, 1, 0, 0, 0)))
+    // T = X1 Wbt^T (the forward's stage A; taken from the caller when it kept phonlp_label_project's), then dX2 at the
+    // heads and its scatter to the heads' rows
+    if (!T_opt && (rc = launch_linear("bw:label_T", XF, 2L * KP, Wbt, KP, nullptr, T, OK, M, OK, KP, 0, nullptr, 0, st, nullptr,
+                                      1, 0, 0, 0)))
         return rc;
     {
         ProfScope ps("bw_label_dx2", st);
-        hipLaunchKernelGGL(bw_label_dx2h_kernel, dim3(M), dim3(256), 0, st, g, T, KP, O, dX2h);
+        hipLaunchKernelGGL(bw_label_dx2h_kernel, dim3(M), dim3(256), 0, st, g, T_opt ? T_opt : T, KP, O, dX2h);
         hipLaunchKernelGGL(bw_label_scatter_kernel, dim3(M), dim3(256), 0, st, dX2h, gold_head, sentlens, L, KP, dXF);
         if ((rc = check_launch("bw_label_dx2_kernel"))) return rc;
     }

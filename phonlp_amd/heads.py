@@ -340,7 +340,7 @@ class TaskHeads:
             if G is not None:
                 first_layers(name, dW12a, db12a, s_ * 2 * KP)
         # the label scorer: its loss reads the scores at the gold heads
-        dXFl, dWbtl = ops.label_backward(XF, w.lab_Wbt, d_label, gh, lens, H, O)
+        dXFl, dWbtl = ops.label_backward(XF, w.lab_Wbt, d_label, gh, lens, H, O, T)
         grads["deprel.scorer.W_bilin.weight"] = unpack_bilinear(dWbtl, O)
         dh_lab, dW12l, db12l = ops.linear_backward(hm, w.lab_W12, XF, dXFl, True)
         first_layers("deprel", dW12l, db12l, 0)

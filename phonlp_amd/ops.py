@@ -430,9 +430,9 @@ def softmax_rows_backward(P: Tensor, dP: Tensor) -> Tensor:
 
 
 def label_backward(XF: Tensor, Wbt: Tensor, g: Tensor, gold_head: Tensor, sentlens: Tensor, H: int,
-                   O: int) -> Tuple[Tensor, Tensor]:
+                   O: int, T: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
     """Backward of the label scorer's scores at the gold heads: g [B,L,O] (dep_loss_grad's d_label), XF [B*L, 2*KP], Wbt
-    [O*KP, KP] -> (dXF [B*L, 2*KP], dWbt [O*KP, KP])."""
+    [O*KP, KP], T = label_project's second output when kept (else recomputed) -> (dXF [B*L, 2*KP], dWbt [O*KP, KP])."""
     _need(XF, torch.float32, "XF")
     _need(Wbt, torch.float32, "Wbt")
     _need(g, torch.float32, "g")
@@ -447,8 +447,12 @@ def label_backward(XF: Tensor, Wbt: Tensor, g: Tensor, gold_head: Tensor, sentle
     dWbt = torch.empty((O * KP, KP), dtype=torch.float32, device=dev)
     nb = lib().phonlp_label_backward_ws_bytes(B, L, H, O)
     ws = torch.empty((nb,), dtype=torch.uint8, device=dev)
-    check(lib().phonlp_label_backward(_p(XF), _p(Wbt), _p(g), _p(gold_head), _p(sentlens), B, L, H, O, _p(dXF), _p(dWbt),
-                                      _p(ws), nb, _stream()), "phonlp_label_backward")
+    if T is not None:
+        _need(T, torch.float32, "T")
+        if T.numel() != B * L * O * KP:
+            raise ValueError("label_backward: T must be [B*L, O*KP]")
+    check(lib().phonlp_label_backward(_p(XF), _p(Wbt), _p(T), _p(g), _p(gold_head), _p(sentlens), B, L, H, O, _p(dXF),
+                                      _p(dWbt), _p(ws), nb, _stream()), "phonlp_label_backward")
     return dXF, dWbt
 
 

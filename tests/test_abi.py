@@ -107,9 +107,9 @@ def test_argument_errors_without_gpu(heads_lib):
     assert heads_lib.phonlp_bilinear_backward(one, one, None, 2, 8, 400, one, one, one, 1 << 30, None) == -1
     assert heads_lib.phonlp_bilinear_backward(one, one, one, 2, 8, 400, one, one, one, 16, None) == -2
     assert heads_lib.phonlp_bilinear_backward(ctypes.c_void_p(one.value + 4), one, one, 2, 8, 400, one, one, one, 1 << 30, None) == -1
-    assert heads_lib.phonlp_label_backward(one, one, one, None, one, 2, 8, 400, 33, one, one, one, 1 << 30, None) == -1
-    assert heads_lib.phonlp_label_backward(one, one, one, one, one, 2, 2000, 400, 33, one, one, one, 1 << 40, None) == -1  # L > 1024
-    assert heads_lib.phonlp_label_backward(one, one, one, one, one, 2, 8, 400, 33, one, one, one, 16, None) == -2
+    assert heads_lib.phonlp_label_backward(one, one, None, one, None, one, 2, 8, 400, 33, one, one, one, 1 << 30, None) == -1
+    assert heads_lib.phonlp_label_backward(one, one, None, one, one, one, 2, 2000, 400, 33, one, one, one, 1 << 40, None) == -1  # L > 1024
+    assert heads_lib.phonlp_label_backward(one, one, None, one, one, one, 2, 8, 400, 33, one, one, one, 16, None) == -2
     assert b"label_backward" in heads_lib.phonlp_last_error()
     assert heads_lib.phonlp_softmax_rows(None, 4, 24, one, None) == -1 and heads_lib.phonlp_softmax_rows(one, 4, 2000, one, None) == -1
     assert heads_lib.phonlp_softmax_rows_backward(one, None, 4, 24, one, None) == -1
