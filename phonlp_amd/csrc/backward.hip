@@ -221,8 +221,8 @@ extern "C" int phonlp_linear_backward(const float *X, int ldx, const float *W, i
     if (!X || !W || !dY || M <= 0 || N <= 0 || K <= 0 || ldx < K || ldw < K || lddy < N || (relu && (!Yact || ldy < N)) ||
         (dX && lddx < K) || (dW && lddw < K))
         return fail(PHONLP_ERR_SHAPE, "linear_backward: bad argument");
-    if (!ws || ws_bytes < phonlp_linear_backward_ws_bytes(M, N, K))
-        return fail(PHONLP_ERR_WORKSPACE, "linear_backward: workspace too small");
+    if (!ws || ((uintptr_t)ws & 15) || ws_bytes < phonlp_linear_backward_ws_bytes(M, N, K))
+        return fail(PHONLP_ERR_WORKSPACE, "linear_backward: workspace too small or not 16-byte aligned");
     hipStream_t st = as_stream(stream);
     const int N4 = up4(N), G = ceil_div(M, 128);
     const SplitK sk = plan_splitk(N, K, M);
@@ -278,8 +278,8 @@ extern "C" int phonlp_bilinear_backward(const float *XF, const float *Wbt, const
         return fail(PHONLP_ERR_SHAPE, "bilinear_backward: bad argument");
     if (((uintptr_t)XF & 15) || ((uintptr_t)Wbt & 15) || ((uintptr_t)dXF & 15))
         return fail(PHONLP_ERR_SHAPE, "bilinear_backward: XF, Wbt, dXF must be 16-byte aligned");
-    if (!ws || ws_bytes < phonlp_bilinear_backward_ws_bytes(B, L, H))
-        return fail(PHONLP_ERR_WORKSPACE, "bilinear_backward: workspace too small");
+    if (!ws || ((uintptr_t)ws & 15) || ws_bytes < phonlp_bilinear_backward_ws_bytes(B, L, H))
+        return fail(PHONLP_ERR_WORKSPACE, "bilinear_backward: workspace too small or not 16-byte aligned");
     hipStream_t st = as_stream(stream);
     const int KP = kp_of(H), M = B * L, L4 = up4(L);
     const SplitK sk = plan_splitk(KP, KP, M);
@@ -340,8 +340,8 @@ extern "C" int phonlp_label_backward(const float *XF, const float *Wbt, const fl
         return fail(PHONLP_ERR_SHAPE, "label_backward: bad argument (L <= 1024)");
     if (((uintptr_t)XF & 15) || ((uintptr_t)Wbt & 15) || ((uintptr_t)dXF & 15))
         return fail(PHONLP_ERR_SHAPE, "label_backward: XF, Wbt, dXF must be 16-byte aligned");
-    if (!ws || ws_bytes < phonlp_label_backward_ws_bytes(B, L, H, O))
-        return fail(PHONLP_ERR_WORKSPACE, "label_backward: workspace too small");
+    if (!ws || ((uintptr_t)ws & 15) || ws_bytes < phonlp_label_backward_ws_bytes(B, L, H, O))
+        return fail(PHONLP_ERR_WORKSPACE, "label_backward: workspace too small or not 16-byte aligned");
     hipStream_t st = as_stream(stream);
     const int KP = kp_of(H), M = B * L, M4 = up4(M), OK = O * KP;
     char *p = (char *)ws;
