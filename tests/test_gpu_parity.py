@@ -49,6 +49,8 @@ def _close(got, want, rtol=2e-4, atol=2e-5):
     (300, 70, 868, True, False), (129, 9, 868, True, True), (64, 416, 416, False, False),
     (1000, 868, 868, False, True), (257, 24, 400, False, True), (1500, 300, 868, True, True), (1027, 129, 20, False, False),
     (2048, 128, 4, False, False), (128, 128, 32, True, False), (5, 3, 4, False, False),
+    # narrow layers over many rows (the one-wavefront 32-row tiles)
+    (4100, 24, 400, False, True), (5000, 40, 868, True, True), (4096, 9, 20, True, False), (4099, 64, 36, False, False),
 ])
 def test_linear_vs_torch_fp32(dev, engine, M, N, K, relu, masked):
     from phonlp_amd import ops
