@@ -849,3 +849,157 @@ def pos_head_split(enc: Tensor, sentlens: Tensor, Whid: Tensor, bhid: Tensor, Wc
                                       H, U, TE, _p(feat) if want_feat else None, _p(planes), _p(inv), _p(pos), _p(logits),
                                       _p(ws), nb, _stream()), "phonlp_pos_head_split")
     return planes, inv, pos, logits, feat
+
+
+# ---- shape functions (torch.library `register_fake`) for the ops above that had none: with them every custom op of
+# the head path traces under FakeTensorMode / torch.compile without running a kernel (VERDICT r1, row b).  Each returns
+# what the op itself allocates -- same shapes and dtypes; tests/test_fake_ops.py checks them against the real outputs.
+_I32, _I64, _U8 = torch.int32, torch.int64, torch.uint8
+
+
+@linear.register_fake
+def _(x, weight, bias, relu, sentlens, L):
+    return x.new_empty((x.shape[0], weight.shape[0]))
+
+
+@pack_scorer.register_fake
+def _(W1, b1, W2, b2, Wbil):
+    H, D = W1.shape
+    KP = kp(H)
+    return W1.new_empty((2 * KP, D)), W1.new_empty((2 * KP,)), W1.new_empty((Wbil.shape[2] * KP, KP))
+
+
+@pos_head.register_fake
+def _(enc, sentlens, Whid, bhid, Wclf, bclf, emb):
+    B, L, E = enc.shape
+    return (enc.new_empty((B, L, E + emb.shape[1])), enc.new_empty((B, L), dtype=_I32),
+            enc.new_empty((B, L, Wclf.shape[0])))
+
+
+@tagger_head.register_fake
+def _(enc, sentlens, Whn, bhn, Wclf, bclf, emb, Wner_emb, bner):
+    B, L, _ = enc.shape
+    return (enc.new_empty((B, L), dtype=_I32), enc.new_empty((B, L, Wner_emb.shape[0])),
+            enc.new_empty((B, L, Wclf.shape[0])))
+
+
+@ner_emission.register_fake
+def _(feat, sentlens, Wner, bner):
+    return feat.new_empty((feat.shape[0], feat.shape[1], Wner.shape[0]))
+
+
+@dep_hidden.register_fake
+def _(feat, sentlens, Wdep, bdep):
+    return torch.empty_like(feat)
+
+
+@deep_biaffine_arc.register_fake
+def _(hidden, W12, b12, Wbt, H, n_scorers, use_lin, use_dist, want_raw, pad_sentlens=None, b12_pad=None):
+    B, L, _ = hidden.shape
+    return hidden.new_empty((B, L, L)), hidden.new_empty((3, B, L, L) if want_raw else (0,))
+
+
+@deep_biaffine_label.register_fake
+def _(hidden, W12, b12, Wbt, H, O, want_scores, pad_sentlens=None, b12_pad=None):
+    B, L, _ = hidden.shape
+    return hidden.new_empty((B, L, L), dtype=_I32), hidden.new_empty((B, L, O, L) if want_scores else (0,))
+
+
+@crf_viterbi.register_fake
+def _(logits, trans, sentlens):
+    B, L, _ = logits.shape
+    return logits.new_empty((B, L), dtype=_I32), logits.new_empty((B,))
+
+
+@crf_log_partition.register_fake
+def _(logits, trans, pad_mask, sentlens, gold):
+    B = logits.shape[0]
+    return logits.new_empty((B,)), logits.new_empty((B,)), logits.new_empty((B,))
+
+
+@mst_one_root.register_fake
+def _(arc, sentlens):
+    B, L, _ = arc.shape
+    return arc.new_empty((B, L), dtype=_I32), arc.new_empty((B,), dtype=_I32)
+
+
+@label_project.register_fake
+def _(hidden, W12, b12, Wbt, H, O, pad_sentlens=None, b12_pad=None):
+    B, L, _ = hidden.shape
+    KP = kp(H)
+    return hidden.new_empty((B * L, 2 * KP)), hidden.new_empty((B * L, O * KP))
+
+
+def _fake_rels(like, heads):
+    B, L = heads.shape
+    return like.new_empty((B, L), dtype=_I32), like.new_empty((B, L), dtype=torch.float32)
+
+
+@label_at_heads.register_fake
+def _(T, XF, heads, sentlens, H, O):
+    return _fake_rels(T, heads)
+
+
+@label_at_heads_rows4.register_fake
+def _(T4, XF, heads, sentlens, H, O):
+    return _fake_rels(T4, heads)
+
+
+@label_at_heads_fused.register_fake
+def _(x1p, x1_inv, wbtcp, wbtc_inv, XF, heads, sentlens, H, O):
+    return _fake_rels(XF, heads)
+
+
+@gather_labels.register_fake
+def _(label_argmax, heads, sentlens):
+    return torch.empty_like(heads)
+
+
+@gather_first_subword.register_fake
+def _(enc, first_subword, sentlens):
+    return enc.new_empty((enc.shape[0], first_subword.shape[1], enc.shape[2]))
+
+
+@eval_counts.register_fake
+def _(pos, ner, heads, rels, gold_pos, gold_ner, gold_head, gold_rel, lens_tag, lens_dep, mst_status):
+    return pos.new_empty((8,), dtype=_I64)
+
+
+@eval_counts_into.register_fake
+def _(counts, pos, ner, heads, rels, gold_pos, gold_ner, gold_head, gold_rel, lens_tag, lens_dep, mst_status):
+    return None
+
+
+@ner_entity_counts_into.register_fake
+def _(counts, pred, gold, sentlens, tag_kind, tag_type):
+    return None
+
+
+@split_rows.register_fake
+def _(x):
+    rows, K = x.shape
+    return x.new_empty((rows, lib().phonlp_split_bytes(1, K)), dtype=_U8), x.new_empty((rows,))
+
+
+@linear_split.register_fake
+def _(xp, x_inv, wp, w_inv, bias, K, relu, sentlens, L, pad_bias, kind):
+    return x_inv.new_empty((xp.shape[0], wp.shape[0]))
+
+
+@biaffine_arc_scores.register_fake
+def _(XF, B, L, Wbt, H, n_scorers, use_lin, use_dist):
+    return XF.new_empty((B, L, L))
+
+
+@label_stage_a_split.register_fake
+def _(x1p, x1_inv, wbtp, wbt_inv, B, L, H, O, ones_col=None):
+    return x1_inv.new_empty((lib().phonlp_label_t4_bytes(B, L, H, O) // 4,))
+
+
+@pos_head_split.register_fake
+def _(enc, sentlens, Whid, bhid, Wclf, bclf, emb, want_feat):
+    B, L, E = enc.shape
+    D = E + emb.shape[1]
+    return (enc.new_empty((B * L, lib().phonlp_split_bytes(1, D)), dtype=_U8), enc.new_empty((B * L,)),
+            enc.new_empty((B, L), dtype=_I32), enc.new_empty((B, L, Wclf.shape[0])),
+            enc.new_empty((B, L, D) if want_feat else (0,)))
