@@ -39,6 +39,9 @@ struct MstArgs {
     double *cs_score;      // [B][cslots] best score of the slot's candidates (-inf: none finite)
     int32_t *cs_idx;       // [B][cslots] candidate number of that best (ascending ROOT-child order), -2: decode error
     uint16_t *cs_tree;     // [B][cslots][L] its tree
+    // mst_fast.hip: expansion records, one region of hist_stride bytes per workgroup
+    unsigned char *hist;
+    long hist_stride;
 };
 
 #define PHONLP_MST_PENDING 3   // internal: between the phases of the two-phase form

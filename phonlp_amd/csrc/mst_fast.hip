@@ -53,30 +53,39 @@ namespace phonlp {
 constexpr int kFastSlots = 4;
 constexpr int kWalkMax = 4;
 constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140;
-enum { FS_LO = 0, FS_HI, FS_BAD, FS_FAIL, FS_NNEW, FS_CMD, FS_BAD2, FS_COUNT = 16 };
+enum { FS_LO = 0, FS_HI, FS_BAD, FS_FAIL, FS_NNEW, FS_CMD, FS_BAD2, FS_ROUNDS, FS_COUNT = 16 };
 enum { CMD_GO = 1, CMD_DONE = 2 };
 constexpr int HC_SETTLED = 0x8000, HC_NEW = 0x4000, HC_MASK = 0x3FFF;
 
 struct FastLayout {
-    size_t off_d, off_a, off_i, off_hist, total;
-    int pitch, hist_cap;
+    size_t off_d, off_a, off_i, off_b, total;  // float64 arrays | A, later the staged records | int arrays | byte arrays
+    int pitch, stage_recs;
 };
-constexpr int kFastIntArrays = 13;
+constexpr int kFastIntArrays = 4;   // hcAw, cycf, newlist, bvL
+constexpr int kFastByteArrays = 8;  // comp, bjL, selI, selJ, lab, pool, rI, rJ (word indices < 128)
+// bytes of the A region: L rows of LA, and never fewer than sixteen expansion records (3 LA bytes each)
+__host__ __device__ inline size_t fast_a_bytes(int L) {
+    const size_t LA = (size_t)((L + 3) & ~3);
+    const size_t a = (size_t)L * LA, m = 16 * 3 * LA;
+    return ((a > m ? a : m) + 15) / 16 * 16;
+}
+// LDS per workgroup.  At L = 128: matrix 64 KB (pitch 128: the row scan staggers its column chunks instead of padding
+// the rows), A 16 KB, per-word arrays 6 KB = 86 KB -- so that ONE 72 KB dense-layer block still fits the CU beside a
+// decode (the expansion records, 49 KB at three bytes per word and round, live in the workspace and are staged into
+// the A region, dead by then, for the expansion).
 static FastLayout fast_layout(int L) {
     FastLayout f;
-    f.pitch = (L + 47) / 64 * 64 + 16;  // smallest p >= L with p % 64 == 16: four consecutive rows hit disjoint banks
+    const int LA = (L + 3) & ~3;
+    f.pitch = L <= 64 ? 64 : 128;
     f.off_d = (size_t)L * f.pitch * sizeof(float);
     f.off_a = f.off_d + (size_t)3 * L * sizeof(double);
-    f.off_i = f.off_a + align_up((size_t)L * ((L + 3) & ~3), 16);
-    f.off_hist = f.off_i + ((size_t)kFastIntArrays * L + FS_COUNT) * sizeof(int);
-    const long room = 160L * 1024 - (long)f.off_hist;
-    long cap = room / (3L * L) - 1;
-    if (cap > L) cap = L;
-    f.hist_cap = cap > 0 ? (int)cap : 0;
-    f.total = f.off_hist + (size_t)(f.hist_cap + 1) * 3 * L;
+    f.stage_recs = (int)(fast_a_bytes(L) / (3 * (size_t)LA));
+    f.off_i = f.off_a + fast_a_bytes(L);
+    f.off_b = f.off_i + ((size_t)kFastIntArrays * L + FS_COUNT) * sizeof(int);
+    f.total = align_up(f.off_b + (size_t)kFastByteArrays * LA, 16);
     return f;
 }
-bool mst_fast_fits(int L) { return L >= 2 && L <= 128 && fast_layout(L).hist_cap >= 16; }
+bool mst_fast_fits(int L) { return L >= 2 && L <= 128; }
 
 template <int CTRL>
 __device__ __forceinline__ int fdpp_i(int v) {
@@ -112,18 +121,24 @@ __device__ __forceinline__ void fast_argmax_step_d(double &bv, int &bi, int &dup
 }
 
 // best column of one row among the columns other than `row` itself (and not column 0 when `skip0`), by 16 lanes
+// The four rows a wavefront scans at once lie a multiple of 64 words apart (pitch 64 / 128), so row group `stag` takes
+// its sixteen-column chunks in the order stag, stag + 1, ...: the four groups then read four different bank groups.
+// The order is free: only a strictly unique maximum is ever used (`dup` sends everything else to the fallback).
 template <int NC>
-__device__ __forceinline__ void fast_scan_row16(const float *Wrow, int row, int n, int sub, bool skip0, float &bv,
+__device__ __forceinline__ void fast_scan_row16(const float *Wrow, int row, int n, int sub, int stag, bool skip0, float &bv,
                                                 int &bi, int &dup) {
     float vals[NC];
 #pragma unroll
-    for (int t = 0; t < NC; ++t) vals[t] = (sub + 16 * t < n) ? Wrow[sub + 16 * t] : -__builtin_inff();
+    for (int t = 0; t < NC; ++t) {
+        const int j = sub + 16 * ((t + stag) & (NC - 1));
+        vals[t] = j < n ? Wrow[j] : -__builtin_inff();
+    }
     bv = -__builtin_inff();
     bi = INT_MAX;
     dup = 0;
 #pragma unroll
     for (int t = 0; t < NC; ++t) {
-        const int j = sub + 16 * t;
+        const int j = sub + 16 * ((t + stag) & (NC - 1));
         const bool ok = j < n && j != row && !(skip0 && j == 0);
         const float v = ok ? vals[t] : -__builtin_inff();
         const bool gt = v > bv, eq = ok && v == bv;
@@ -144,7 +159,7 @@ __device__ __forceinline__ void fast_scan_row16(const float *Wrow, int row, int 
 #endif
 
 template <int NPL>
-__global__ __launch_bounds__(256) void mst_fast_kernel(MstArgs a, int pitch, int hist_cap) {
+__global__ __launch_bounds__(256) void mst_fast_kernel(MstArgs a, int pitch, int stage_recs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sub = lane & 15;
 #ifdef MST_STAMPS
@@ -183,12 +198,16 @@ __global__ __launch_bounds__(256) void mst_fast_kernel(MstArgs a, int pitch, int
     double *dlt = selV + L, *offL = dlt + L;
     unsigned char *A = reinterpret_cast<unsigned char *>(offL + L);
     const int LA = (L + 3) & ~3;  // row pitch of A
-    int *comp = reinterpret_cast<int *>(A + align_up((size_t)L * LA, 16));
-    int *bjL = comp + L, *hcAw = bjL + L, *selI = hcAw + L, *selJ = selI + L, *lab = selJ + L, *cycf = lab + L;
-    int *claim = cycf + L, *pool = claim + L, *newlist = pool + L, *rI = newlist + L, *rJ = rI + L;
-    float *bvL = reinterpret_cast<float *>(rJ + L);
+    int *hcAw = reinterpret_cast<int *>(A + fast_a_bytes(L));
+    int *cycf = hcAw + L, *newlist = cycf + L;
+    float *bvL = reinterpret_cast<float *>(newlist + L);
     int *sc = reinterpret_cast<int *>(bvL + L);
-    unsigned char *hist = reinterpret_cast<unsigned char *>(sc + FS_COUNT);
+    unsigned char *comp = reinterpret_cast<unsigned char *>(sc + FS_COUNT);
+    unsigned char *bjL = comp + LA, *selI = bjL + LA, *selJ = selI + LA, *lab = selJ + LA, *pool = lab + LA;
+    unsigned char *rI = pool + LA, *rJ = rI + LA;
+    // expansion records of this workgroup (workspace): record r = planes comp / in-edge row / in-edge column of LA bytes
+    const int RS = 3 * LA;
+    unsigned char *hist = a.hist + (long)blockIdx.x * a.hist_stride;
     const float *arc = a.arc + (long)b * L * L;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const float NEGF = -__builtin_inff();
@@ -267,7 +286,7 @@ __global__ __launch_bounds__(256) void mst_fast_kernel(MstArgs a, int pitch, int
         __syncthreads();
         for (int row = 1 + (tid >> 4); row < l; row += 16) {
             float bv; int bi, dup;
-            fast_scan_row16<4 * NPL>(W + row * pitch, row, l, sub, skip0, bv, bi, dup);
+            fast_scan_row16<4 * NPL>(W + row * pitch, row, l, sub, (tid >> 4) & 3, skip0, bv, bi, dup);
             if (row == root) { bv = 0.f; bi = 0; dup = 0; }  // set_root: the row's only edge, weight 0 (:147-148)
             if (sub == 0) {
                 bjL[row] = bi;
@@ -280,7 +299,9 @@ __global__ __launch_bounds__(256) void mst_fast_kernel(MstArgs a, int pitch, int
         }
         __syncthreads();
         STAMP(1);
-        int fail_ = sc[FS_FAIL];  // block-uniform
+        const int fail0 = sc[FS_FAIL];  // block-uniform: a row without a strictly best finite head
+        int fail_ = fail0;
+        int head[NPL];  // wavefront 0: the decoded heads of the lane's words
         // Contracted row and in-edge of the new components of a round, one component per wavefront (lane = column):
         // per column the best member row (:84,:88,:97; A holds the row, bit 7 = more than one), then the strictly best
         // column outside the component.  Run by all four wavefronts between two workgroup barriers.
@@ -519,17 +540,17 @@ __global__ __launch_bounds__(256) void mst_fast_kernel(MstArgs a, int pitch, int
 #pragma unroll
                 for (int q = 0; q < NPL; ++q) anyf = anyf || found[q];
                 if (!__ballot(anyf)) break;  // no cycle left: the components' in-edges form the tree
-                if (rounds >= hist_cap) { fail_ = 1; break; }
-                // this round's record: components and in-edges BEFORE the merge
+                if (rounds >= L) { fail_ = 1; break; }  // cannot happen: every round removes a component
+                // this round's record: components and in-edges BEFORE the merge (to the workspace: nothing waits for it)
                 {
-                    unsigned char *hr = hist + (long)rounds * 3 * L;
+                    unsigned char *hr = hist + (long)rounds * RS;
 #pragma unroll
                     for (int q = 0; q < NPL; ++q) {
                         const int v = lane + 64 * q;
                         if (v < l) {
                             hr[v] = (unsigned char)mycomp[q];
-                            hr[L + v] = (unsigned char)selIr[q];
-                            hr[2 * L + v] = (unsigned char)selJr[q];
+                            hr[LA + v] = (unsigned char)selIr[q];
+                            hr[2 * LA + v] = (unsigned char)selJr[q];
                         }
                     }
                 }
@@ -634,53 +655,80 @@ __global__ __launch_bounds__(256) void mst_fast_kernel(MstArgs a, int pitch, int
                 STAMP(6);
                 FCOUNT(8, 1);
             }
-            if (lane == 0) sc[FS_CMD] = CMD_DONE;  // releases the helper wavefronts
+            if (!fail_) {  // the components of the final state: record `rounds`
+                unsigned char *hr = hist + (long)rounds * RS;
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) {
+                    const int v = lane + 64 * q;
+                    if (v < l) hr[v] = (unsigned char)mycomp[q];
+                }
+            }
+            if (lane == 0) {
+                sc[FS_CMD] = CMD_DONE;  // releases the helper wavefronts
+                sc[FS_ROUNDS] = fail_ ? -1 : rounds;
+            }
             lds_barrier();
-            if (!fail_) {
-                // ---- expansion: the real in-edge of every component, the rounds undone in reverse
+        }
+        if (!fail0) {
+            // ---- expansion: the real in-edge of every component, the rounds undone in reverse.  The records come back
+            // from the workspace into the A region (dead now), `stage_recs` at a time, fetched by the whole workgroup.
+            __syncthreads();  // wavefront 0's records have reached memory
+            const int R = sc[FS_ROUNDS];  // block-uniform; -1: the rounds gave up
+            unsigned char *curI = selI, *curJ = selJ, *nxtI = rI, *nxtJ = rJ;
+            for (int top = R; top > 0;) {
+                const int lo = top - (stage_recs - 1) > 0 ? top - (stage_recs - 1) : 0;
                 {
-                    unsigned char *hr = hist + (long)rounds * 3 * L;
+                    const unsigned *src = reinterpret_cast<const unsigned *>(hist + (long)lo * RS);
+                    unsigned *dst = reinterpret_cast<unsigned *>(A);
+                    const int nd = (top - lo + 1) * (RS / 4);
+                    for (int t0 = tid; t0 < nd; t0 += 16 * 256) {  // sixteen loads in flight per thread
+                        unsigned v[16];
 #pragma unroll
-                    for (int q = 0; q < NPL; ++q) {
-                        const int v = lane + 64 * q;
-                        if (v < l) hr[v] = (unsigned char)mycomp[q];
+                        for (int u = 0; u < 16; ++u) v[u] = t0 + 256 * u < nd ? src[t0 + 256 * u] : 0u;
+#pragma unroll
+                        for (int u = 0; u < 16; ++u)
+                            if (t0 + 256 * u < nd) dst[t0 + 256 * u] = v[u];
                     }
                 }
-                WFENCE();
-                int *curI = selI, *curJ = selJ, *nxtI = rI, *nxtJ = rJ;
-                int hc0[NPL], hy[NPL], hi_[NPL], hj_[NPL];  // this round's record for the lane's words, loaded one round ahead
-                auto load_record = [&](int s_) {
-                    const unsigned char *hs = hist + (long)s_ * 3 * L, *hn = hs + 3 * L;
+                __syncthreads();
+                if (wave == 0) {
+                    int hc0[NPL], hy[NPL], hi_[NPL], hj_[NPL];  // a round's record for the lane's words, loaded one round ahead
+                    auto load_record = [&](int s_) {
+                        const unsigned char *hs = A + (s_ - lo) * RS, *hn = hs + RS;
 #pragma unroll
-                    for (int q = 0; q < NPL; ++q) {
-                        const int v = (lane + 64 * q < l) ? lane + 64 * q : 0;
-                        hc0[q] = hs[v]; hy[q] = hn[v]; hi_[q] = hs[L + v]; hj_[q] = hs[2 * L + v];
-                    }
-                };
-                if (rounds > 0) load_record(rounds - 1);
-                for (int s = rounds - 1; s >= 0; --s) {
-                    const unsigned char *hs = hist + (long)s * 3 * L;
-                    int c0[NPL], y[NPL], si[NPL], sj[NPL], ri[NPL], rj[NPL];
-#pragma unroll
-                    for (int q = 0; q < NPL; ++q) {
-                        c0[q] = hc0[q]; y[q] = hy[q]; si[q] = hi_[q]; sj[q] = hj_[q];
-                        ri[q] = curI[y[q]]; rj[q] = curJ[y[q]];
-                    }
-                    if (s > 0) load_record(s - 1);
-#pragma unroll
-                    for (int q = 0; q < NPL; ++q) {
-                        const int v = lane + 64 * q;
-                        const bool inside = hs[ri[q]] == v;
-                        if (v >= 1 && v < l && c0[q] == v) {  // a component of this state
-                            nxtI[v] = inside ? ri[q] : si[q];
-                            nxtJ[v] = inside ? rj[q] : sj[q];
+                        for (int q = 0; q < NPL; ++q) {
+                            const int v = (lane + 64 * q < l) ? lane + 64 * q : 0;
+                            hc0[q] = hs[v]; hy[q] = hn[v]; hi_[q] = hs[LA + v]; hj_[q] = hs[2 * LA + v];
                         }
+                    };
+                    load_record(top - 1);
+                    for (int s = top - 1; s >= lo; --s) {
+                        const unsigned char *hs = A + (s - lo) * RS;
+                        int c0[NPL], y[NPL], si[NPL], sj[NPL], ri[NPL], rj[NPL];
+#pragma unroll
+                        for (int q = 0; q < NPL; ++q) {
+                            c0[q] = hc0[q]; y[q] = hy[q]; si[q] = hi_[q]; sj[q] = hj_[q];
+                            ri[q] = curI[y[q]]; rj[q] = curJ[y[q]];
+                        }
+                        if (s > lo) load_record(s - 1);
+#pragma unroll
+                        for (int q = 0; q < NPL; ++q) {
+                            const int v = lane + 64 * q;
+                            const bool inside = hs[ri[q]] == v;
+                            if (v >= 1 && v < l && c0[q] == v) {  // a component of this state
+                                nxtI[v] = (unsigned char)(inside ? ri[q] : si[q]);
+                                nxtJ[v] = (unsigned char)(inside ? rj[q] : sj[q]);
+                            }
+                        }
+                        WFENCE();
+                        unsigned char *t1 = curI; curI = nxtI; nxtI = t1;
+                        unsigned char *t2 = curJ; curJ = nxtJ; nxtJ = t2;
                     }
-                    WFENCE();
-                    int *t1 = curI; curI = nxtI; nxtI = t1;
-                    int *t2 = curJ; curJ = nxtJ; nxtJ = t2;
                 }
-                int head[NPL];
+                top = lo;
+                if (top > 0) __syncthreads();  // the next group of records overwrites this one
+            }
+            if (wave == 0 && R >= 0) {
 #pragma unroll
                 for (int q = 0; q < NPL; ++q) {
                     const int v = lane + 64 * q;
@@ -735,7 +783,7 @@ __global__ __launch_bounds__(256) void mst_fast_kernel(MstArgs a, int pitch, int
                     }
                 }
             }
-            if (lane == 0) sc[FS_FAIL] = fail_;
+            if (tid == 0) sc[FS_FAIL] = fail_;
         }
         __syncthreads();
         fail_ = sc[FS_FAIL];
@@ -796,10 +844,13 @@ int launch_mst_fast_pick(MstArgs a, hipStream_t stream) {  // for mst_round.hip,
     return check_launch("mst_fast_pick_kernel");
 }
 
+// expansion records of one workgroup: up to L rounds + the final state, three planes of LA bytes each
+static size_t fast_hist_stride(int L) { return (size_t)(L + 1) * 3 * ((L + 3) & ~3); }
 size_t mst_fast_bytes(int B, int L) {
     const size_t q = (size_t)B * kFastSlots;
     return align_up((size_t)B * sizeof(int32_t), 256) + align_up(q * sizeof(double), 256) +
-           align_up(q * sizeof(int32_t), 256) + align_up(q * L * sizeof(uint16_t), 256);
+           align_up(q * sizeof(int32_t), 256) + align_up(q * L * sizeof(uint16_t), 256) +
+           align_up(q * fast_hist_stride(L), 256);
 }
 void mst_fast_carve(MstArgs &a, void *base) {
     char *p = (char *)base;
@@ -807,7 +858,9 @@ void mst_fast_carve(MstArgs &a, void *base) {
     a.fb_list = (int32_t *)p;  p += align_up((size_t)a.B * sizeof(int32_t), 256);
     a.cs_score = (double *)p;  p += align_up(q * sizeof(double), 256);
     a.cs_idx = (int32_t *)p;   p += align_up(q * sizeof(int32_t), 256);
-    a.cs_tree = (uint16_t *)p;
+    a.cs_tree = (uint16_t *)p; p += align_up(q * a.L * sizeof(uint16_t), 256);
+    a.hist = (unsigned char *)p;  // one region per workgroup of the larger (second) launch
+    a.hist_stride = (long)fast_hist_stride(a.L);
     a.cslots = kFastSlots;
 }
 
@@ -826,8 +879,8 @@ int launch_mst_fast(MstArgs a, hipStream_t stream) {
     for (int mode = 1; mode <= 2; ++mode) {
         a.mode = mode;
         const dim3 grid(mode == 1 ? a.B : a.B * kFastSlots);
-        if (a.L <= 64) hipLaunchKernelGGL(mst_fast_kernel<1>, grid, dim3(256), f.total, stream, a, f.pitch, f.hist_cap);
-        else hipLaunchKernelGGL(mst_fast_kernel<2>, grid, dim3(256), f.total, stream, a, f.pitch, f.hist_cap);
+        if (a.L <= 64) hipLaunchKernelGGL(mst_fast_kernel<1>, grid, dim3(256), f.total, stream, a, f.pitch, f.stage_recs);
+        else hipLaunchKernelGGL(mst_fast_kernel<2>, grid, dim3(256), f.total, stream, a, f.pitch, f.stage_recs);
         const int rc = check_launch("mst_fast_kernel");
         if (rc) return rc;
     }
