@@ -189,7 +189,7 @@ class TaskHeads:
             "mst_prio": int(env("PHONLP_MST_PRIO", "0")),        # HIP stream priority of the MST stream (-1 = high; see DESIGN.md section 9 before using it)
             "tag_prio": int(env("PHONLP_TAG_PRIO", "0")),        # ... of the tagger stream
             "tagger_fused": env("PHONLP_TAGGER_FUSED", "1") == "1",  # 0: pos_head + ner_emission instead of tagger_head
-            "tagger_late": int(env("PHONLP_TAGGER_LATE", "2")),  # tagger chain start: 0 batch start, 1 arc-done, 2 behind label W1/W2 (default)
+            "tagger_late": int(env("PHONLP_TAGGER_LATE", "-1")),  # tagger chain start: 0 batch start, 1 arc-done, 2 behind label W1/W2; -1 (default): 1 with the MST on the main stream (eager launches), else 2
             "pos_fold": env("PHONLP_POS_FOLD", "1") == "1",      # scorers read [enc ; pos_dis] (K = 792) instead of [enc ; pos_emb]
             "rows4": env("PHONLP_ROWS4", "1") != "0",            # unfused form: T in the rows-by-4 layout
             "ones_col": env("PHONLP_ONES_COL", "1") == "1",      # unfused form: X1's ones column as a per-column bias
@@ -202,6 +202,9 @@ class TaskHeads:
             # ragged batches whose lengths the host knows: the live words packed (no arithmetic on padding); 0 = off,
             # else the largest live fraction (percent) that is still packed
             "pack_pct": int(env("PHONLP_PACK", "90")),
+            # joined fused form: 1 = the MST continues the main stream's queue behind the arc scores and the label
+            # scorer's first layers go to a side stream (0: the MST on a side stream, the label layers on main)
+            "mst_on_main": env("PHONLP_MST_ON_MAIN", "1") == "1",
         }
         self._side = None
         # what the arc scorers' first layer gives a padded word (zero hidden row): relu of the layer's own bias
@@ -502,8 +505,8 @@ class TaskHeads:
         cfg = self.cfg
         if self._side is None:
             self._side = (torch.cuda.Stream(priority=cfg["tag_prio"]), torch.cuda.Stream(priority=cfg["mst_prio"]),
-                          torch.cuda.Stream())
-        s_tag, s_mst, s_fin = self._side
+                          torch.cuda.Stream(), torch.cuda.Stream())
+        s_tag, s_mst, s_fin, s_lab = self._side
         pack = self._pack_plan(enc_dep, sentlens_dep, enc_tag, sentlens_tag)
         lens_d = as_sentlens(sentlens_dep, enc_dep.device)
         lens_t = as_sentlens(sentlens_tag, enc_tag.device)
@@ -536,8 +539,15 @@ class TaskHeads:
         # per step); PHONLP_TAGGER_LATE=0 (A/B) starts it beside the parser's own POS head and arc GEMMs instead
         split = ops.get_gemm_engine() == 2 and w.lab_Wbt_s is not None
         # A/B (2): behind the label scorer's W1/W2 layer (engine 2 path only)
-        tagger_later = split and cfg["tagger_late"] == 2
-        tagger_late = cfg["tagger_late"] >= 1
+        # the MST on the main stream's queue (joined, fused form; see below): decided here because the tagger chain's
+        # default starting point depends on it
+        mst_main = cfg["mst_on_main"] and join and split and cfg["label_fused"] and enc_dep.shape[1] <= cfg["fused_max_len"]
+        # (under graph capture the streams become a DAG and the launch order no longer decides who reaches the CUs first:
+        # there the tagger chain behind the label layers is the better start, 2.45 against 2.58 ms per replay)
+        tl = cfg["tagger_late"] if cfg["tagger_late"] >= 0 else (
+            1 if mst_main and not torch.cuda.is_current_stream_capturing() else 2)
+        tagger_later = split and tl == 2
+        tagger_late = tl >= 1
         if not tagger_late and not tagger_later:
             start = torch.cuda.Event()
             start.record(main)
@@ -582,24 +592,40 @@ class TaskHeads:
         if tagger_late and not tagger_later:
             tag, ner, tag_done = run_tagger(arc_done)
         # MST beside the label scorer
-        s_mst.wait_event(arc_done)
-        arc_logp.record_stream(s_mst)
-        lens_d.record_stream(s_mst)
-        with torch.cuda.stream(s_mst):
+        if mst_main:
+            # The decode continues the main stream's queue: it starts a few microseconds behind the arc scores, BEFORE the
+            # label layers' blocks (side stream, one event away) reach the CUs, and those then run beside it.
+            s_lab.wait_event(arc_done)
+            for t in (featp, feati, lens_d):
+                t.record_stream(s_lab)
             heads, status = ops.mst_one_root(arc_logp, lens_d)
-            mst_done = torch.cuda.Event()
-            mst_done.record(s_mst)
+            mst_done, lab_stream = None, s_lab
+        else:
+            s_mst.wait_event(arc_done)
+            arc_logp.record_stream(s_mst)
+            lens_d.record_stream(s_mst)
+            with torch.cuda.stream(s_mst):
+                heads, status = ops.mst_one_root(arc_logp, lens_d)
+                mst_done = torch.cuda.Event()
+                mst_done.record(s_mst)
+            lab_stream = main
         if split:
-            if pack:
-                XF = ops.linear_split(featp, feati, labW[0], labW[1], w.lab_b12f, D, True, None, 0, None, 2)
-            else:
-                XF = ops.linear_split(featp, feati, labW[0], labW[1], w.lab_b12f, D, True, lens_d, Ld,
-                                      w.lab_b12, 2)
-            x1p, x1i = ops.split_rows(XF[:, :ops.kp(w.H)])
+            with torch.cuda.stream(lab_stream):
+                if pack:
+                    XF = ops.linear_split(featp, feati, labW[0], labW[1], w.lab_b12f, D, True, None, 0, None, 2)
+                else:
+                    XF = ops.linear_split(featp, feati, labW[0], labW[1], w.lab_b12f, D, True, lens_d, Ld,
+                                          w.lab_b12, 2)
+                x1p, x1i = ops.split_rows(XF[:, :ops.kp(w.H)])
+                if tagger_later or mst_main:
+                    w12_done = torch.cuda.Event()
+                    w12_done.record(lab_stream)
             if tagger_later:
-                w12_done = torch.cuda.Event()
-                w12_done.record(main)
                 tag, ner, tag_done = run_tagger(w12_done)
+            if mst_main:
+                main.wait_event(w12_done)
+                for t in (XF, x1p, x1i):
+                    t.record_stream(main)
             rows4 = cfg["rows4"]
             # Fused form (stage A after the MST with the labels-at-heads contraction in its epilogue): T (1.8 GB at the
             # headline size) is neither written nor read.  It needs the heads, so it waits for the MST -- affordable since
@@ -623,7 +649,8 @@ class TaskHeads:
             fin.wait_event(proj_done)
             for t in (XF, T, lens_d, lens_t):
                 t.record_stream(fin)
-        fin.wait_event(mst_done)
+        if mst_done is not None:
+            fin.wait_event(mst_done)
         for t in (heads, status, ner, tag["pos_pred"]):
             t.record_stream(fin)
         # labels only where annotate() reads them: at the decoded heads (ref annotate_model.py:263-266)
