@@ -289,6 +289,9 @@ int phonlp_crf_nll_grad_static(const float *logits, const float *trans, const ui
  * call.  phonlp_set_mst_fast_path(0) sends every sentence to the reference-order kernel (A/B and tests; process-wide,
  * not thread-safe); phonlp_mst_fallback_counter_offset gives the byte offset inside `ws` of an int32 that holds, after
  * the call, how many sentences were handed over (-1 if the round-based kernel does not apply to this L).
+ * The workspace also holds the round-based decoder's expansion records (3 bytes per word and round, kept out of LDS
+ * so that a dense-layer block fits a CU beside a decode): phonlp_mst_ws_bytes(256, 128) is 90 MB, 51 MB of it records.  Two calls
+ * that overlap on one GPU need a workspace each.
  */
 size_t phonlp_mst_ws_bytes(int B, int L);
 int phonlp_mst_one_root(const float *arc, const int32_t *sentlens, int B, int L,
