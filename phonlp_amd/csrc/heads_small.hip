@@ -66,6 +66,8 @@ int launch_linear(const char *tag, const float *X, long ldx, const float *W, lon
 struct LinearArgs;
 int gemm_engine();
 int launch_split_rows(const float *X, long ldx, int rows, int K, void *planes, long pitch, float *inv_scale, hipStream_t stream);
+int launch_split_rows2(const float *X, long ldx, int rows, void *planes, long pitch, float *inv_scale, const float *X2,
+                       long ldx2, int rows2, void *planes2, float *inv_scale2, int K, hipStream_t stream);
 int launch_linear_f16x3(const char *tag, const void *Xp, long pitch_x, const float *x_inv, const void *Wp, long pitch_w,
                         const float *w_inv, const float *bias, float *Y, long ldy, int M, int N, int K16, int relu,
                         const int32_t *sentlens, int L, hipStream_t stream, const float *pad_bias, int rows4 = 0,
@@ -333,9 +335,7 @@ static int pos_head_impl(const float *enc, int ld_enc, const int32_t *sentlens, 
             encp = feat_planes; enci = feat_inv_scale; pitch = 4L * ((E + TE + 15) / 16 * 16);
             presplit = 1;
         }
-        rc = launch_split_rows(enc, ld_enc, M, E, encp, pitch, enci, st);
-        if (rc) return rc;
-        rc = launch_split_rows(Whid, E, H, E, whp, 0, whi, st);
+        rc = launch_split_rows2(enc, ld_enc, M, encp, pitch, enci, Whid, E, H, whp, whi, E, st);
         if (rc) return rc;
         rc = launch_linear_f16x3("linear:upos_hid", encp, pitch, enci, whp, 4L * K16e, whi, bhid, hid, H, M, H, K16e, 1,
                                  sentlens, L, st, nullptr);
@@ -408,9 +408,7 @@ extern "C" int phonlp_tagger_head(const float *enc, int ld_enc, const int32_t *s
         void *whp = p;              p += align_up(phonlp_split_bytes(N, E), 256);
         float *whi = (float *)p;
         const int K16e = (E + 15) / 16 * 16;
-        rc = launch_split_rows(enc, ld_enc, M, E, encp, 0, enci, st);
-        if (rc) return rc;
-        rc = launch_split_rows(Whn, E, N, E, whp, 0, whi, st);
+        rc = launch_split_rows2(enc, ld_enc, M, encp, 0, enci, Whn, E, N, whp, whi, E, st);
         if (rc) return rc;
         rc = launch_linear_f16x3("linear:upos_hid", encp, 4L * K16e, enci, whp, 4L * K16e, whi, bhn, hid, HN, M, N, K16e, -H,
                                  sentlens, L, st, nullptr);

@@ -36,10 +36,26 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // ------------------------------------------------------------------------------------------ split
 // One wavefront per row.  K % 4 == 0, X 16-byte aligned, ldx % 4 == 0.
 // `pitch` = bytes between image rows (>= 4*K16: the image may be the leading columns of a wider one).
-__global__ __launch_bounds__(256) void split_rows_kernel(const float *X, long ldx, int rows, int K, int K16,
-                                                          unsigned char *planes, long pitch, float *inv_scale) {
+// A launch splits one matrix or two of the same K (b.rows > 0: an activation and the weight it meets, one launch
+// instead of two on the step's critical chain).
+struct SplitSet {
+    const float *X;
+    long ldx;
+    int rows;
+    unsigned char *planes;
+    long pitch;
+    float *inv_scale;
+};
+__global__ __launch_bounds__(256) void split_rows_kernel(SplitSet a, SplitSet b, int K, int K16) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nb1 = (a.rows + 3) >> 2;
+    const bool second = (int)blockIdx.x >= nb1;  // block-uniform
+    const float *X = second ? b.X : a.X;
+    const long ldx = second ? b.ldx : a.ldx, pitch = second ? b.pitch : a.pitch;
+    const int rows = second ? b.rows : a.rows;
+    unsigned char *planes = second ? b.planes : a.planes;
+    float *inv_scale = second ? b.inv_scale : a.inv_scale;
+    const int row = ((int)blockIdx.x - (second ? nb1 : 0)) * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float *x = X + (long)row * ldx;
     unsigned mx = 0;
@@ -1174,8 +1190,24 @@ int launch_split_rows(const float *X, long ldx, int rows, int K, void *planes, l
     if ((K & 3) || (ldx & 3) || ((uintptr_t)X & 15) || ((uintptr_t)planes & 15) || (pitch & 15) || pitch < 4L * K16)
         return fail(PHONLP_ERR_SHAPE, "split_rows: K, ldx must be multiples of 4 and X, planes 16-byte aligned");
     ProfScope ps("split_rows", stream);
-    hipLaunchKernelGGL(split_rows_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, stream, X, ldx, rows, K, K16,
-                       reinterpret_cast<unsigned char *>(planes), pitch, inv_scale);
+    const SplitSet a{X, ldx, rows, reinterpret_cast<unsigned char *>(planes), pitch, inv_scale}, none{};
+    hipLaunchKernelGGL(split_rows_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, stream, a, none, K, K16);
+    return check_launch("split_rows_kernel");
+}
+// Two matrices of the same K in one launch (packed image of the second).
+int launch_split_rows2(const float *X, long ldx, int rows, void *planes, long pitch, float *inv_scale, const float *X2,
+                       long ldx2, int rows2, void *planes2, float *inv_scale2, int K, hipStream_t stream) {
+    if (!X || !planes || !inv_scale || !X2 || !planes2 || !inv_scale2 || rows <= 0 || rows2 <= 0 || K <= 0)
+        return fail(PHONLP_ERR_SHAPE, "split_rows: bad argument");
+    const int K16 = (K + 15) / 16 * 16;
+    if (pitch == 0) pitch = 4L * K16;
+    if ((K & 3) || (ldx & 3) || (ldx2 & 3) || ((uintptr_t)X & 15) || ((uintptr_t)X2 & 15) || ((uintptr_t)planes & 15) ||
+        ((uintptr_t)planes2 & 15) || (pitch & 15) || pitch < 4L * K16)
+        return fail(PHONLP_ERR_SHAPE, "split_rows: K, ldx must be multiples of 4 and X, planes 16-byte aligned");
+    ProfScope ps("split_rows", stream);
+    const SplitSet a{X, ldx, rows, reinterpret_cast<unsigned char *>(planes), pitch, inv_scale};
+    const SplitSet b{X2, ldx2, rows2, reinterpret_cast<unsigned char *>(planes2), 4L * K16, inv_scale2};
+    hipLaunchKernelGGL(split_rows_kernel, dim3(ceil_div(rows, 4) + ceil_div(rows2, 4)), dim3(256), 0, stream, a, b, K, K16);
     return check_launch("split_rows_kernel");
 }
 }  // namespace phonlp
