@@ -488,9 +488,12 @@ class TaskHeads:
         out["done"]).
 
         With `overlap` the three independent chains run on separate HIP streams: the tagger chain (POS head,
-        NER emissions, Viterbi) and the MST decode (which only needs the arc log-probs) run beside the label
-        scorer's GEMMs.  The decoders are dependent chains that leave most of a CU idle; sharing the chip with
-        the MFMA-bound label path hides them.
+        NER emissions, Viterbi), the MST decode (which only needs the arc log-probs) and the label scorer's first
+        layers.  The decoders are dependent chains that leave most of a CU idle (an MST workgroup holds 86 KB of LDS
+        and four wavefronts, so one dense-layer block fits beside it); sharing the chip with the MFMA-bound label
+        path hides them.  Joined form: the MST continues the calling stream's queue and the label layers run from a
+        side stream; streaming form: the MST on a side stream, the label layers on the calling stream (DESIGN.md
+        section 5).
         """
         if not overlap:
             dep = self.parser(enc_dep, sentlens_dep, want_label_argmax=False)
@@ -535,12 +538,10 @@ class TaskHeads:
                 tag_done.record(s_tag)
             return tag, ner, tag_done
 
-        # The tagger chain starts when the arc scores are done, beside the MST and stage A (measured: 3.64 vs 3.71 ms
-        # per step); PHONLP_TAGGER_LATE=0 (A/B) starts it beside the parser's own POS head and arc GEMMs instead
         split = ops.get_gemm_engine() == 2 and w.lab_Wbt_s is not None
-        # A/B (2): behind the label scorer's W1/W2 layer (engine 2 path only)
         # the MST on the main stream's queue (joined, fused form; see below): decided here because the tagger chain's
-        # default starting point depends on it
+        # default starting point depends on it.  Tagger chain start (cfg tagger_late): 1 = when the arc scores are done,
+        # 2 = behind the label scorer's W1/W2 layer (engine 2 path only), 0 = at the start of the batch (A/B)
         mst_main = cfg["mst_on_main"] and join and split and cfg["label_fused"] and enc_dep.shape[1] <= cfg["fused_max_len"]
         # (under graph capture the streams become a DAG and the launch order no longer decides who reaches the CUs first:
         # there the tagger chain behind the label layers is the better start, 2.45 against 2.58 ms per replay)
