@@ -167,11 +167,8 @@ __global__ __launch_bounds__(256) void mst_fast_kernel(MstArgs a, int pitch, int
     long long stamp_t = clock64();
 #endif
     const int L = a.L, mode = a.mode, CS = a.cslots;
-    const int b = mode == 2 ? blockIdx.x / CS : blockIdx.x;
+    int b = mode == 2 ? blockIdx.x / CS : blockIdx.x;
     const int slot = mode == 2 ? blockIdx.x % CS : 0;
-    int l = a.sentlens[b];
-    if (l > L) l = L;
-    int32_t *hout = a.heads + (long)b * L;
     int ncand = 1;
     if (mode == 2) {
         // The shared region of the reference-order kernel (its counters, candidate queue and per-sentence counts) is
@@ -183,10 +180,39 @@ __global__ __launch_bounds__(256) void mst_fast_kernel(MstArgs a, int pitch, int
             if (tid == 0) a.cand_left[b] = 0;
             if (b == 0 && tid < CT_COUNT) a.ctr[tid] = 0;
         }
-        if (a.status[b] != PHONLP_MST_PENDING) return;
+        // Workgroups (r, slot) decode the r-th PENDING sentence (ascending), not sentence r: the few workgroups with a
+        // decode to run are then the FIRST of the grid and are placed first -- a workgroup needs 86 KB of a CU, and
+        // beside another stream's dense layers those are scarce; spread over the grid, the decodes queued behind
+        // hundreds of workgroups that only come to leave again.
+        // (five words of the scalar block `sc` below, free until the decode starts)
+        int *sel = reinterpret_cast<int *>(smem_raw + (size_t)L * pitch * sizeof(float) + (size_t)3 * L * sizeof(double) +
+                                           fast_a_bytes(L)) + 4 * L + 8;
+        const int rank = b;
+        if (tid < 5) sel[tid] = tid == 4 ? -1 : 0;
+        __syncthreads();
+        int before = 0;  // pending sentences in front of this chunk of 256
+        for (int c0 = 0; c0 < a.B; c0 += 256) {
+            const int t = c0 + tid;
+            const bool pend = t < a.B && a.status[t] == PHONLP_MST_PENDING;
+            const unsigned long long bal = __ballot(pend);
+            if (lane == 0) sel[wave] = __popcll(bal);
+            __syncthreads();
+            int pre = before;
+            for (int w = 0; w < wave; ++w) pre += sel[w];
+            if (pend && pre + __popcll(bal & ((1ull << lane) - 1ull)) == rank) sel[4] = t;
+            before += sel[0] + sel[1] + sel[2] + sel[3];
+            __syncthreads();
+            if (sel[4] >= 0 || before > rank) break;  // block-uniform
+        }
+        b = sel[4];
+        if (b < 0) return;  // fewer than rank + 1 pending sentences
         ncand = a.cand_n[b];
         if (slot >= ncand) return;
-    } else {
+    }
+    int l = a.sentlens[b];
+    if (l > L) l = L;
+    int32_t *hout = a.heads + (long)b * L;
+    if (mode != 2) {
         for (int t = tid; t < L; t += 256) hout[t] = 0;
         if (l <= 1) {  // l == 1: ROOT only -- the reference hits its broken assert (no candidate root)
             if (tid == 0) a.status[b] = l == 1 ? PHONLP_MST_NO_FINITE_TREE : PHONLP_MST_OK;
