@@ -677,7 +677,7 @@ class TaskHeads:
 
 
 class CapturedStep:
-    """`TaskHeads.annotate_batch` at ONE shape as a HIP graph: the step's ~26 launches on three streams become one
+    """`TaskHeads.annotate_batch` at ONE shape as a HIP graph: the step's 21 launches on three streams become one
     `hipGraphLaunch`, so a loop that calls the heads at a fixed (bucketed) shape pays one launch per batch (B=1, L=32:
     0.40 against 0.46 ms; B=32, L=64: 0.57 against 0.59; tools/graph_probe.py).
 
