@@ -19,7 +19,7 @@
 //      column is a maximum over old columns and is ordered last).  By induction over the rounds the tree is unique,
 //      and any correct variant of the algorithm -- the reference's included -- returns it.
 //
-//  A sentence that fails (G) or (U) anywhere (ties, denormals, NaN, more rounds than the history holds) gets status
+//  A sentence that fails (G) or (U) anywhere (ties, denormals, NaN) gets status
 //  PHONLP_MST_FALLBACK and is decoded by the reference-order kernel afterwards (launch_mst_wave over the fallback
 //  list).  Integer-valued or zero matrices (all ties) therefore take the old path; float log-probabilities take this one.
 //
@@ -37,7 +37,8 @@
 // steps (load + exactness check, first arg-max of every row).
 //
 // Expansion (:105-128 in one sweep per round, backwards): per round the component of every word and the in-edge of
-// every component BEFORE the merge are kept (3 bytes per word and round); a component keeps the real in-edge of the
+// every component BEFORE the merge are kept (3 bytes per word and round, in the workspace; staged back into LDS for the
+// sweep); a component keeps the real in-edge of the
 // component it was merged into if that edge enters one of its own words, and its own recorded in-edge otherwise.
 //
 // Single-root logic (:137-169) as in mst.hip's two-phase form: phase 1 decodes the unconstrained tree of every
