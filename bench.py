@@ -94,6 +94,90 @@ def cpu_baseline(sd, enc_dep, enc_tag, lens_dep, lens_tag, n_sample=32):
     }
 
 
+def launch_ranks(n, argv):
+    """`bench.py --gpus N` with N > 1 and no external launcher: start N fresh rank processes of this script (one per GPU,
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, rendezvous on 127.0.0.1), relay rank 0's JSON line and
+    return non-zero if any rank does.  The parent makes no GPU call, before or after: the children are fresh processes
+    (subprocess), never a re-exec of a process that has touched the GPU.  The reference has no counterpart (no
+    parallelism); the north star asks for the number at 1/2/4/8 GPUs."""
+    import socket
+    import subprocess
+    import threading
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool (RCCL needs it)
+        procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+
+    def relay():  # rank 0 prints the result line; the other ranks' stdout goes to stderr
+        for line in procs[0].stdout:
+            sys.stdout.write(line.decode(errors="replace"))
+            sys.stdout.flush()
+
+    th = threading.Thread(target=relay, daemon=True)
+    th.start()
+    rc = 0
+    live = set(range(n))
+    while live and rc == 0:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is not None:
+                live.discard(r)
+                if code != 0:
+                    rc = code if code > 0 else 128 - code
+                    print(f"bench.py: rank {r} exited with {code}", file=sys.stderr, flush=True)
+        time.sleep(0.05)
+    for r in live:  # a rank failed: the others would wait in a collective forever -- end exactly the PIDs started here
+        procs[r].terminate()
+    for r in live:
+        try:
+            procs[r].wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            procs[r].kill()
+    th.join(timeout=5)
+    return rc
+
+
+def dry_run(args, rank, world):
+    """PHONLP_BENCH_DRYRUN=1 (tests/test_bench_launch.py, CPU): the multi-rank SKELETON of this script -- rank start-up,
+    rendezvous, batch sharding, the count all-reduce, MAX of the elapsed times, rank 0's line -- over gloo with NO head
+    work at all: every rank only tallies the sentences of the batches it would have walked.  Never a reported number."""
+    import torch.distributed as dist
+    from phonlp_amd.sharding import shard_batches
+    if os.environ.get("PHONLP_BENCH_DRYRUN_FAIL_RANK") == str(rank):  # the launcher's failure path under test
+        sys.exit(3)
+    if world > 1:
+        dist.init_process_group(backend="gloo")
+    counts = torch.zeros(11, dtype=torch.int64)
+    t0 = time.perf_counter()
+    if args.corpus > 0:
+        n_batches = (args.corpus + B - 1) // B
+        for i in shard_batches(n_batches, rank, world):
+            counts[0] += min(B, args.corpus - i * B)
+        steps, expect = n_batches, args.corpus
+    else:
+        counts[0] = B * args.steps
+        steps, expect = args.steps, B * args.steps * world
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(counts)
+        dist.all_reduce(t, dist.ReduceOp.MAX)
+    if rank == 0:
+        assert int(counts[0]) == expect, f"eval counts inconsistent: {counts.tolist()}"
+        print(json.dumps({"metric": "dry run (no head work)", "value": None, "unit": "sentences/s", "n_gpus": world,
+                          "steps": steps, "warmup": args.warmup, "data": "DRY RUN: launcher / rendezvous / reduction only",
+                          "eval_counts": {"sentences": int(counts[0])}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -106,12 +190,20 @@ def main():
                          "--steps/--warmup are ignored")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:  # no external launcher: this process only starts the ranks, it never touches a GPU
+            sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks")
+
     if os.environ.get("PHONLP_BENCH_DEBUG"):  # where is every rank after N seconds? (hang diagnosis)
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["PHONLP_BENCH_DEBUG"]), exit=True)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("PHONLP_BENCH_DRYRUN", "0") == "1":
+        return dry_run(args, rank, world)
     # PHONLP_BENCH_REHEARSAL=1: rehearse the multi-rank code path on a one-GPU box (every rank on cuda:0, gloo instead
     # of RCCL, which refuses two ranks on one device); never used for reported numbers
     rehearsal = os.environ.get("PHONLP_BENCH_REHEARSAL", "0") == "1"
