@@ -25,6 +25,11 @@
 // depend on who decoded what.  A workgroup with nothing to pop and no own sentence left exits (waiting for late
 // pushes was measured and dropped: the waiters' LDS keeps other streams' GEMMs off their CUs), so the grid always
 // drains; whoever pushes candidates pops them itself if nobody else does.
+//
+// Forward progress: NO loop in this kernel waits on another workgroup without a bound.  The pop reads an entry before
+// it takes it (entries are written once per call), the re-read of a reserved-but-unwritten entry and the fallback
+// launch's look-out for late candidates are both counted down; when a count runs out the workgroup goes on (or
+// leaves) and the work stays with the workgroup that produced it.  The result never depends on who decoded what.
 #include <type_traits>
 
 #include "mst.h"
@@ -173,6 +178,7 @@ __global__ __launch_bounds__(256) void mst_wave_kernel(MstArgs a, int stack_cap)
     int own_k = wg;
     if (tid == 0) atomicAdd(&a.ctr[CT_STARTED], 1);
     int b = 0, slot = -1, root = -1;  // current task: sentence, candidate slot (-1 = the unconstrained decode)
+    int wait_budget = 8192;           // polls this workgroup may still spend looking for other sentences' candidates
 #ifdef MST_STAMPS
     long long stamp_acc[16] = {0};
     long long stamp_t = clock64();
@@ -193,23 +199,35 @@ __global__ __launch_bounds__(256) void mst_wave_kernel(MstArgs a, int stack_cap)
     for (;;) {  // one task per trip: a candidate popped from the shared queue if there is one, else the next own sentence
         if (tid == 0) {
             int code = -1;
-            for (;;) {
+            // Pop: a queue entry is written ONCE per call (0 -> code + 1) and read BEFORE the head is advanced past it,
+            // so nobody ever owns an entry it cannot read yet.  An entry that is reserved (tail advanced) but not
+            // stored yet is re-read a bounded number of times and then left to its pusher, which pops what it pushed
+            // once its own sentence is done: no workgroup waits on another one without a bound.
+            for (int tries = 0;;) {
                 const int h = ld_i32(&a.ctr[CT_Q_HEAD]), t = ld_i32(&a.ctr[CT_Q_TAIL]);
                 if (h >= t) break;
-                if (atomicCAS(&a.ctr[CT_Q_HEAD], h, h + 1) == h) {
-                    int v;
-                    while ((v = ld_i32(&a.tasks[h])) == 0) __builtin_amdgcn_s_sleep(2);  // pusher is mid-store
+                const int v = ld_i32(&a.tasks[h]);
+                if (v == 0) {
+                    if (++tries > 64) break;
+                    __builtin_amdgcn_s_sleep(2);
+                    continue;
+                }
+                if (atomicCAS(&a.ctr[CT_Q_HEAD], h, h + 1) == h) {  // fails at most once per entry someone else took
                     code = v - 1;
                     break;
                 }
             }
             if (code < 0 && own_k < nown) code = -2 - own_k;
             // Fallback list only (few sentences on a small grid: a sentence's candidates would otherwise all be decoded
-            // by the workgroup that owns it): with nothing to do, wait for candidates while some sentence's
-            // unconstrained decode is still running -- but only once every workgroup of the grid has started, i.e. all
-            // of them are resident and none needs this one's CU; otherwise leave, so the grid always drains.
+            // by the workgroup that owns it): with nothing to do, look for candidates a little longer while some
+            // sentence's unconstrained decode is still running -- only once every workgroup of the grid has started
+            // (all of them are resident, none needs this one's CU), and only for a BOUNDED number of polls
+            // (wait_budget, ~1 us each, per workgroup and launch): a workgroup that runs out leaves, and whoever pushes
+            // candidates pops them itself, so the grid drains whatever the scheduler does with the other workgroups.
             if (code == -1 && a.fb_list) {
-                while (ld_i32(&a.ctr[CT_STARTED]) >= (int)gridDim.x && ld_i32(&a.ctr[CT_FIRST_DONE]) < nown) {
+                while (wait_budget > 0 && ld_i32(&a.ctr[CT_STARTED]) >= (int)gridDim.x &&
+                       ld_i32(&a.ctr[CT_FIRST_DONE]) < nown) {
+                    --wait_budget;
                     __builtin_amdgcn_s_sleep(32);
                     const int h = ld_i32(&a.ctr[CT_Q_HEAD]), t = ld_i32(&a.ctr[CT_Q_TAIL]);
                     if (h < t) { code = INT_MIN; break; }  // something was pushed: go round again and pop it

@@ -186,8 +186,6 @@ class TaskHeads:
         # what the tests run
         env = os.environ.get
         self.cfg = {
-            "mst_prio": int(env("PHONLP_MST_PRIO", "0")),        # HIP stream priority of the MST stream (-1 = high; see DESIGN.md section 9 before using it)
-            "tag_prio": int(env("PHONLP_TAG_PRIO", "0")),        # ... of the tagger stream
             "tagger_fused": env("PHONLP_TAGGER_FUSED", "1") == "1",  # 0: pos_head + ner_emission instead of tagger_head
             "tagger_late": int(env("PHONLP_TAGGER_LATE", "-1")),  # tagger chain start: 0 batch start, 1 arc-done, 2 behind label W1/W2; -1 (default): 1 with the MST on the main stream (eager launches), else 2
             "pos_fold": env("PHONLP_POS_FOLD", "1") == "1",      # scorers read [enc ; pos_dis] (K = 792) instead of [enc ; pos_emb]
@@ -507,8 +505,8 @@ class TaskHeads:
         main = torch.cuda.current_stream()
         cfg = self.cfg
         if self._side is None:
-            self._side = (torch.cuda.Stream(priority=cfg["tag_prio"]), torch.cuda.Stream(priority=cfg["mst_prio"]),
-                          torch.cuda.Stream(), torch.cuda.Stream())
+            # all at the default HIP priority (a high-priority MST stream was tried in round 2 and removed: DESIGN.md section 9)
+            self._side = (torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream())
         s_tag, s_mst, s_fin, s_lab = self._side
         pack = self._pack_plan(enc_dep, sentlens_dep, enc_tag, sentlens_tag)
         lens_d = as_sentlens(sentlens_dep, enc_dep.device)
