@@ -43,8 +43,13 @@ class SyntheticCorpus:
             "enc_tag": torch.randn(b, L - 1, self.E, generator=g, device=device),
         }
         if self.ragged:
-            lens = torch.randint(max(2, L // 4), L + 1, (b,), generator=g, device=device, dtype=torch.int32)
-            lens = torch.sort(lens, descending=True)[0].contiguous()
+            # drawn on the HOST (a few hundred integers): the reference's loader knows every sentence's length on the
+            # host too (annotate_model.py:440-467), and host-known lengths are what lets annotate_batch pack the live words
+            gh = torch.Generator().manual_seed(self.seed + i)
+            lens_h = torch.sort(torch.randint(max(2, L // 4), L + 1, (b,), generator=gh, dtype=torch.int32),
+                                descending=True)[0]
+            lens = lens_h.to(device)
+            out["lens_dep_host"], out["lens_tag_host"] = lens_h.tolist(), (lens_h - 1).tolist()
         else:
             lens = torch.full((b,), L, dtype=torch.int32, device=device)
         out["lens_dep"], out["lens_tag"] = lens, lens - 1
@@ -72,7 +77,9 @@ def walk(heads, corpus: SyntheticCorpus, rank: int = 0, world: int = 1, device=N
     sentences = 0
     for i in shard_batches(last - first, rank, world):
         bt = corpus.batch(first + i, dev)
-        out = heads.annotate_batch(bt["enc_dep"], bt["lens_dep"], bt["enc_tag"], bt["lens_tag"], join=not streaming)
+        # ragged batches hand over their lengths as host lists (the packed path needs them to size its launches)
+        out = heads.annotate_batch(bt["enc_dep"], bt.get("lens_dep_host", bt["lens_dep"]), bt["enc_tag"],
+                                   bt.get("lens_tag_host", bt["lens_tag"]), join=not streaming)
         with torch.cuda.stream(out["tag_stream"]):
             for k in ("gold_ner", "lens_tag"):
                 bt[k].record_stream(out["tag_stream"])

@@ -671,7 +671,8 @@ class TaskHeads:
             done = torch.cuda.Event()
             done.record(fin)
         return {"pos": tag["pos_pred"], "ner": ner, "heads": heads, "rels": rels, "mst_status": status,
-                "stream": fin, "done": done, "tag_done": tag_done, "tag_stream": s_tag}
+                "stream": fin, "done": done, "tag_done": tag_done, "tag_stream": s_tag,
+                "arc_logp": arc_logp}  # the scores the heads were decoded from (diagnostics, tests)
 
 
 class CapturedStep:
