@@ -42,6 +42,8 @@ struct MstArgs {
     // mst_fast.hip: expansion records, one region of hist_stride bytes per workgroup
     unsigned char *hist;
     long hist_stride;
+    // mst_fast.hip / mst_round.hip: the margin of the sentence (mst_margin), written by phase 1, read by phase 2 and the pick
+    double *tau;           // [B]
 };
 
 #define PHONLP_MST_PENDING 3   // internal: between the phases of the two-phase form
@@ -64,6 +66,13 @@ enum { CT_STARTED = 0, CT_FIRST_DONE = 1, CT_Q_TAIL = 2, CT_Q_HEAD = 3, CT_FB = 
 #endif
 
 #define NEG_INF_D (-__builtin_inf())
+
+// The margin of the round-based decoders (mst_fast.hip's header has the argument): a selection is used only if its
+// maximum beats every other option by MORE than tau = 16 l^3 2^-53 max|entry|.  The reference's own float64 rounding
+// (and these kernels') moves the weight of the tree it returns by at most ~10 l^2 2^-53 max|entry|, a factor ~l below.
+__host__ __device__ inline double mst_margin(int l, float amax) {
+    return 16.0 * (double)l * (double)l * (double)l * 1.1102230246251565e-16 * (double)amax;
+}
 
 // numpy's float64 pairwise add-reduction order (verified against numpy 2.2, n = 1..1000).
 __device__ inline double np_sum_block(const double *a, int n) {

@@ -4,24 +4,33 @@
 // mst.hip replay that order bit for bit and need ~100 dependent levels per 128-word sentence.  This kernel finds the
 // same tree with ~40 much cheaper rounds, and is used only where it PROVABLY returns the reference's tree:
 //
-//  (G) exactness.  Every finite entry of the sentence's matrix (rows >= 1, off the diagonal) is a multiple of
-//      2^lo with |entry| < 2^hi, and hi - lo + ceil(log2 l) + 1 <= 52.  Every value the reference forms in float64 --
-//      contracted entries (s - e) + total (:84), cycle sums (:75), tree scores (:158) -- is, in exact arithmetic, a
-//      signed sum of at most 2l original entries, so under (G) none of its additions rounds: the reference runs EXACT
-//      Chu-Liu-Edmonds (with its own tie-breaking) and returns A maximum arborescence.  The same holds for the sums
-//      formed here.
-//  (U) uniqueness.  Every selection made here -- the best head of a row among the columns outside its component, the
-//      best row of a component -- has a strictly unique, finite maximum.  Then the maximum arborescence is unique:
-//      if every node of the current contracted graph has a strictly best in-edge and those edges close a cycle C,
-//      every maximum arborescence contains all of C's edges but one (re-hanging the other members of C on their cycle
-//      edge strictly improves any other tree), so maximum arborescences of the graph and of the graph with C
-//      contracted correspond one to one; contracting C leaves the strict maxima of all other rows strict (the new
-//      column is a maximum over old columns and is ordered last).  By induction over the rounds the tree is unique,
-//      and any correct variant of the algorithm -- the reference's included -- returns it.
+//  (M) margin.  Every selection made here -- the best head of a row among the columns outside its component, the best
+//      member row of a contracted column that is chosen, the best column of a new component, the best single-root
+//      candidate -- beats every other option by MORE than tau = 16 l^3 2^-53 max|entry| (mst_margin(); entries: the
+//      finite ones of rows >= 1 off the diagonal; NaN or +inf anywhere: fallback).
 //
-//  A sentence that fails (G) or (U) anywhere (ties, denormals, NaN) gets status
-//  PHONLP_MST_FALLBACK and is decoded by the reference-order kernel afterwards (launch_mst_wave over the fallback
-//  list).  Integer-valued or zero matrices (all ties) therefore take the old path; float log-probabilities take this one.
+//  Why that suffices (u = 2^-53, A = max|entry|, every value anyone forms is a sum of at most l entries, so |value| <= lA):
+//  1. Uniqueness with a margin.  If every node of the current contracted graph has a best in-edge that beats its other
+//     in-edges by g, and those edges close a cycle C, any arborescence can be re-hung to contain all of C's edges but
+//     one (keep the in-edge of the first member of C on a path from ROOT, give every other member its cycle edge), and
+//     every edge changed gains at least g; arborescences that contain all of C but one edge correspond one to one,
+//     weight for weight, to arborescences of the graph with C contracted (:84), where the other nodes' margins are
+//     unchanged (the new column is a maximum over old columns) and the new node's in-edge and the member row behind a
+//     chosen column are checked here.  By induction over the rounds (disjoint cycles of a round commute): the tree T*
+//     decoded here is THE maximum arborescence, and every other arborescence weighs less by at least the smallest margin
+//     seen, i.e. by more than tau minus this kernel's own rounding (its compared values carry <= ~3 l^2 u A).
+//  2. The reference returns a near-maximum arborescence.  It compares stored float64 values exactly (np.argmax); what
+//     rounds are the entries it forms per contraction, (s - e_m) + sum(e) (:73-84): at most (c + 4) u lA off per entry
+//     for a cycle of c members.  A tree of the contracted graph uses ONE such entry, so by induction over its recursion
+//     (exact Chu-Liu-Edmonds on the entries as stored, the optimum of a level equal to that of its exact contraction)
+//     the tree it returns is within sum over levels of 2 (c + 4) u lA <= 10 l^2 u A of the maximum -- a factor ~l
+//     below tau.  Hence it returns T*.  The same for each single-root candidate (:143-160), whose tree scores (l-term
+//     float64 sums, <= l^2 u A off) it compares with strict '>': the pick here requires the best candidate to lead by tau.
+//
+//  No exactness is assumed: scores of any dynamic range qualify (a trained parser's near-certain arcs, log-probabilities
+//  from -1e-7 to -50 in one row, never fit a common grid).  A sentence that fails (M) anywhere -- exact ties above all:
+//  integer-valued or zero matrices -- gets status PHONLP_MST_FALLBACK and is decoded by the reference-order kernel
+//  afterwards (launch_mst_wave over the fallback list), whose tie-breaking IS the reference's.
 //
 // Formulation.  The matrix is never rewritten.  comp[i] = component (contracted node) of word i; off[i] = what the
 // reference has added to row i's entries so far (for every member m of a contracted cycle: total - e_m, :84), which is
@@ -98,36 +107,44 @@ __device__ __forceinline__ double fdpp_d(double v) {
     const int lo = fdpp_i<CTRL>((int)(b & 0xFFFFFFFFll)), hi = fdpp_i<CTRL>((int)(b >> 32));
     return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
-// (value, index, duplicate) arg-max over the 16 lanes of a row: greatest value; `dup` set when the maximum is not unique
+// Margin bookkeeping of every arg-max here: `dup` = "the runner-up is within tau of the maximum" (tau = 0: an exact
+// tie).  Folding a value v into (bv, dup): a new maximum resets dup to (v - bv <= tau), anything else ORs in
+// (bv - v <= tau); merging two partial results keeps the winner's flag and ORs in the distance of the two maxima.
+// -inf operands give +inf or NaN differences, which compare false: "no edge" is never a runner-up.
+//
+// (value, index, near-duplicate) arg-max over the 16 lanes of a row
 template <int CTRL>
-__device__ __forceinline__ void fast_argmax_step(float &bv, int &bi, int &dup) {
+__device__ __forceinline__ void fast_argmax_step(float &bv, int &bi, int &dup, float tau) {
     const float v2 = __int_as_float(fdpp_i<CTRL>(__float_as_int(bv)));
     const int i2 = fdpp_i<CTRL>(bi);
     const int d2 = fdpp_i<CTRL>(dup);
-    const bool gt = v2 > bv, eq = v2 == bv;
-    dup = gt ? d2 : (eq ? 1 : dup);
-    bi = gt ? i2 : ((eq && i2 < bi) ? i2 : bi);
-    bv = gt ? v2 : bv;
-}
-// the same for the contracted rows: (value, column | row byte << 8, duplicate)
-template <int CTRL>
-__device__ __forceinline__ void fast_argmax_step_d(double &bv, int &bi, int &dup) {
-    const double v2 = fdpp_d<CTRL>(bv);
-    const int i2 = fdpp_i<CTRL>(bi);
-    const int d2 = fdpp_i<CTRL>(dup);
-    const bool gt = v2 > bv, eq = v2 == bv;
-    dup = gt ? d2 : (eq ? 1 : dup);
+    const bool gt = v2 > bv;
+    const int near = ((gt ? v2 - bv : bv - v2) <= tau) ? 1 : 0;
+    dup = (gt ? d2 : dup) | near;
     bi = gt ? i2 : bi;
     bv = gt ? v2 : bv;
+}
+// the same for the contracted rows: (value, column | row byte << 8, near-duplicate)
+__device__ __forceinline__ void fast_argmax_merge_d(double &bv, int &bi, int &dup, double v2, int i2, int d2, double tau) {
+    const bool gt = v2 > bv;
+    const int near = ((gt ? v2 - bv : bv - v2) <= tau) ? 1 : 0;
+    dup = (gt ? d2 : dup) | near;
+    bi = gt ? i2 : bi;
+    bv = gt ? v2 : bv;
+}
+template <int CTRL>
+__device__ __forceinline__ void fast_argmax_step_d(double &bv, int &bi, int &dup, double tau) {
+    fast_argmax_merge_d(bv, bi, dup, fdpp_d<CTRL>(bv), fdpp_i<CTRL>(bi), fdpp_i<CTRL>(dup), tau);
 }
 
 // best column of one row among the columns other than `row` itself (and not column 0 when `skip0`), by 16 lanes
 // The four rows a wavefront scans at once lie a multiple of 64 words apart (pitch 64 / 128), so row group `stag` takes
 // its sixteen-column chunks in the order stag, stag + 1, ...: the four groups then read four different bank groups.
-// The order is free: only a strictly unique maximum is ever used (`dup` sends everything else to the fallback).
+// The order is free: only a maximum that beats every other entry by more than tau is ever used (`dup` sends everything
+// else to the fallback).
 template <int NC>
-__device__ __forceinline__ void fast_scan_row16(const float *Wrow, int row, int n, int sub, int stag, bool skip0, float &bv,
-                                                int &bi, int &dup) {
+__device__ __forceinline__ void fast_scan_row16(const float *Wrow, int row, int n, int sub, int stag, bool skip0, float tau,
+                                                float &bv, int &bi, int &dup) {
     float vals[NC];
 #pragma unroll
     for (int t = 0; t < NC; ++t) {
@@ -142,15 +159,16 @@ __device__ __forceinline__ void fast_scan_row16(const float *Wrow, int row, int 
         const int j = sub + 16 * ((t + stag) & (NC - 1));
         const bool ok = j < n && j != row && !(skip0 && j == 0);
         const float v = ok ? vals[t] : -__builtin_inff();
-        const bool gt = v > bv, eq = ok && v == bv;
-        dup = gt ? 0 : (dup | (eq ? 1 : 0));
+        const bool gt = v > bv;
+        const int near = (ok && (gt ? v - bv : bv - v) <= tau) ? 1 : 0;  // fp32 differences of near values are exact
+        dup = gt ? near : (dup | near);
         bi = gt ? j : bi;
         bv = gt ? v : bv;
     }
-    fast_argmax_step<DPP_XOR1>(bv, bi, dup);
-    fast_argmax_step<DPP_XOR2>(bv, bi, dup);
-    fast_argmax_step<DPP_HALF_MIRROR>(bv, bi, dup);
-    fast_argmax_step<DPP_MIRROR>(bv, bi, dup);
+    fast_argmax_step<DPP_XOR1>(bv, bi, dup, tau);
+    fast_argmax_step<DPP_XOR2>(bv, bi, dup, tau);
+    fast_argmax_step<DPP_HALF_MIRROR>(bv, bi, dup, tau);
+    fast_argmax_step<DPP_MIRROR>(bv, bi, dup, tau);
 }
 
 #ifdef MST_STAMPS
@@ -239,11 +257,13 @@ __global__ __launch_bounds__(256) void mst_fast_kernel(MstArgs a, int pitch, int
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const float NEGF = -__builtin_inff();
 
-    // ---- whole workgroup: the matrix into LDS (fp32, as given) and, in phase 1, the exactness test (G)
-    if (tid == 0) { sc[FS_LO] = INT_MAX; sc[FS_HI] = INT_MIN; sc[FS_BAD] = 0; }
+    // ---- whole workgroup: the matrix into LDS (fp32, as given) and, in phase 1, the scale of the margin: the largest
+    // finite |entry| of the rows >= 1 off the diagonal (NaN and +inf have no place in the argument: fallback)
+    if (tid == 0) { sc[FS_LO] = 0; sc[FS_BAD] = 0; }
     __syncthreads();
     {
-        int lo = INT_MAX, hi = INT_MIN, bad = 0;
+        unsigned amax = 0;  // bits of the largest finite |entry| (non-negative floats order like their bits)
+        int bad = 0;
         for (int i0 = wave; i0 < l; i0 += 64) {  // sixteen rows' loads in flight per wavefront: the HBM / L2 latency is paid twice
             float vals[16][NPL];
 #pragma unroll
@@ -262,43 +282,37 @@ __global__ __launch_bounds__(256) void mst_fast_kernel(MstArgs a, int pitch, int
                         W[i * pitch + j] = vals[r][q];
                         if (i >= 1 && i != j) {
                             const unsigned bits = __float_as_uint(vals[r][q]);
-                            const int e = (bits >> 23) & 0xFF;
-                            const unsigned man = bits & 0x7FFFFFu;
-                            if (e == 255) { if (man != 0 || !(bits >> 31)) bad = 1; }      // NaN, +inf (-inf = no edge)
-                            else if (e == 0) { if (man != 0) bad = 1; }                    // denormal (zero is on every grid)
-                            else {
-                                const int tz = __builtin_ctz(man | 0x800000u);
-                                const int elo = e - 150 + tz, ehi = e - 126;
-                                lo = elo < lo ? elo : lo;
-                                hi = ehi > hi ? ehi : hi;
-                            }
+                            const unsigned mag = bits & 0x7FFFFFFFu;
+                            if (mag >= 0x7F800000u) { if (mag != 0x7F800000u || !(bits >> 31)) bad = 1; }  // NaN, +inf (-inf = no edge)
+                            else amax = mag > amax ? mag : amax;
                         }
                     }
                 }
         }
         if (mode == 1) {
-            if (lo != INT_MAX) { atomicMin(&sc[FS_LO], lo); atomicMax(&sc[FS_HI], hi); }
+            if (amax) atomicMax(reinterpret_cast<unsigned *>(&sc[FS_LO]), amax);
             if (bad) sc[FS_BAD] = 1;
         }
     }
     __syncthreads();
+    double tau;
     if (mode == 1) {
-        int nbits = 1;
-        while ((1 << (nbits - 1)) < l) ++nbits;  // ceil(log2 l) + 1
-        const int lo = sc[FS_LO], hi = sc[FS_HI];
-        const int q = lo < 0 ? -lo : 0;
-        const bool exact = !sc[FS_BAD] && (lo == INT_MAX || hi + q + nbits <= 52);
         STAMP(0);
-        if (!exact) {  // block-uniform
+        if (sc[FS_BAD]) {  // block-uniform
             if (tid == 0) {
                 a.status[b] = PHONLP_MST_FALLBACK;
-                a.cand_n[b] = 1;  // why (diagnostics; the pick kernel lists the sentence): 1 = (G)
+                a.cand_n[b] = 1;  // why (diagnostics; the pick kernel lists the sentence): 1 = NaN / +inf entries
             }
             return;
         }
+        tau = mst_margin(l, __uint_as_float((unsigned)sc[FS_LO]));
+        if (tid == 0) a.tau[b] = tau;
+    } else {
+        tau = a.tau[b];
     }
+    const float tauf = __double2float_ru(tau);
 
-    double best_score = NEG_INF_D;
+    double best_score = NEG_INF_D, second_score = NEG_INF_D;
     int best_ci = -1, failed = 0;
     for (int ci = slot; ci < ncand; ci += CS) {  // phase 1: one trip; phase 2: this slot's candidates
         const int root = mode == 2 ? a.cand_root[(long)b * L + ci] : -1;
@@ -313,7 +327,7 @@ __global__ __launch_bounds__(256) void mst_fast_kernel(MstArgs a, int pitch, int
         __syncthreads();
         for (int row = 1 + (tid >> 4); row < l; row += 16) {
             float bv; int bi, dup;
-            fast_scan_row16<4 * NPL>(W + row * pitch, row, l, sub, (tid >> 4) & 3, skip0, bv, bi, dup);
+            fast_scan_row16<4 * NPL>(W + row * pitch, row, l, sub, (tid >> 4) & 3, skip0, tauf, bv, bi, dup);
             if (row == root) { bv = 0.f; bi = 0; dup = 0; }  // set_root: the row's only edge, weight 0 (:147-148)
             if (sub == 0) {
                 bjL[row] = bi;
@@ -367,13 +381,17 @@ __global__ __launch_bounds__(256) void mst_fast_kernel(MstArgs a, int pitch, int
                     }
 #pragma unroll
                     for (int q = 0; q < NPL; ++q) {  // selects, not control flow
+                        // bit 7 of the row byte: another member row comes within tau of the best one (checked if the
+                        // column is chosen); a member's own byte brings its bit along
                         const double v0 = (double)w0[q] + o0[q];
-                        const bool gt0 = v0 > cv[q], eq0 = v0 == cv[q];
-                        ca[q] = gt0 ? a0[q] : (ca[q] | (eq0 ? 0x80 : 0));  // bit 7: two rows attain it (checked if chosen)
+                        const bool gt0 = v0 > cv[q];
+                        const int n0 = ((gt0 ? v0 - cv[q] : cv[q] - v0) <= tau) ? 0x80 : 0;
+                        ca[q] = (gt0 ? a0[q] : ca[q]) | n0;
                         cv[q] = gt0 ? v0 : cv[q];
                         const double v1 = two ? (double)w1[q] + o1[q] : NEG_INF_D;
-                        const bool gt1 = v1 > cv[q], eq1 = two && v1 == cv[q];
-                        ca[q] = gt1 ? a1[q] : (ca[q] | (eq1 ? 0x80 : 0));
+                        const bool gt1 = v1 > cv[q];
+                        const int n1 = ((gt1 ? v1 - cv[q] : cv[q] - v1) <= tau) ? 0x80 : 0;
+                        ca[q] = (gt1 ? a1[q] : ca[q]) | n1;
                         cv[q] = gt1 ? v1 : cv[q];
                     }
                 }
@@ -385,24 +403,19 @@ __global__ __launch_bounds__(256) void mst_fast_kernel(MstArgs a, int pitch, int
                     if (j < l) A[R * LA + j] = (unsigned char)ca[q];
                     const bool ok = j < l && ccol[q] != R && !(skip0 && j == 0);
                     const double v = ok ? cv[q] : NEG_INF_D;
-                    const bool gt = v > bv, eq = ok && v == bv;
-                    dup = gt ? 0 : (dup | (eq ? 1 : 0));
+                    const bool gt = v > bv;
+                    const int near = (ok && (gt ? v - bv : bv - v) <= tau) ? 1 : 0;
+                    dup = gt ? near : (dup | near);
                     bi = gt ? (j | (ca[q] << 8)) : bi;
                     bv = gt ? v : bv;
                 }
-                fast_argmax_step_d<DPP_XOR1>(bv, bi, dup);
-                fast_argmax_step_d<DPP_XOR2>(bv, bi, dup);
-                fast_argmax_step_d<DPP_HALF_MIRROR>(bv, bi, dup);
-                fast_argmax_step_d<DPP_MIRROR>(bv, bi, dup);
+                fast_argmax_step_d<DPP_XOR1>(bv, bi, dup, tau);
+                fast_argmax_step_d<DPP_XOR2>(bv, bi, dup, tau);
+                fast_argmax_step_d<DPP_HALF_MIRROR>(bv, bi, dup, tau);
+                fast_argmax_step_d<DPP_MIRROR>(bv, bi, dup, tau);
 #pragma unroll
-                for (int o = 16; o <= 32; o <<= 1) {
-                    const double v2 = __shfl_xor(bv, o);
-                    const int i2 = __shfl_xor(bi, o), d2 = __shfl_xor(dup, o);
-                    const bool gt = v2 > bv, eq = v2 == bv;
-                    dup = gt ? d2 : (eq ? 1 : dup);
-                    bi = gt ? i2 : bi;
-                    bv = gt ? v2 : bv;
-                }
+                for (int o = 16; o <= 32; o <<= 1)
+                    fast_argmax_merge_d(bv, bi, dup, __shfl_xor(bv, o), __shfl_xor(bi, o), __shfl_xor(dup, o), tau);
                 if (lane == 0) {
                     selI[R] = (bi >> 8) & 0x7F;
                     selJ[R] = bi & 0xFF;
@@ -788,7 +801,8 @@ __global__ __launch_bounds__(256) void mst_fast_kernel(MstArgs a, int pitch, int
                         a.status[b] = PHONLP_MST_PENDING;
                     }
                 } else {
-                    // ---- a candidate's score (ref :155-158): exact, so the order of the additions is free
+                    // ---- a candidate's score (ref :155-158); its rounding (and the reference's, whose sum runs in another
+                    // order) is far inside the margin the scores are compared with
                     double s = 0.0;
 #pragma unroll
                     for (int q = 0; q < NPL; ++q) {
@@ -798,7 +812,8 @@ __global__ __launch_bounds__(256) void mst_fast_kernel(MstArgs a, int pitch, int
 #pragma unroll
                     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
                     s += (double)W[root * pitch];
-                    if (s > best_score) {  // strict: the first best candidate of this slot (ascending) wins
+                    second_score = s > best_score ? best_score : (s > second_score ? s : second_score);
+                    if (s > best_score) {  // the slot's best candidate; a runner-up within tau sends the sentence to the fallback
                         best_score = s;
                         best_ci = ci;
                         uint16_t *tr = a.cs_tree + ((long)b * CS + slot) * L;
@@ -829,14 +844,16 @@ __global__ __launch_bounds__(256) void mst_fast_kernel(MstArgs a, int pitch, int
             }
         } else {
             const long qx = (long)b * CS + slot;
+            if (best_score - second_score <= tau) failed = 1;  // (-inf scores: the difference is +inf or NaN, both false)
             a.cs_score[qx] = failed ? NEG_INF_D : best_score;
             a.cs_idx[qx] = failed ? -2 : best_ci;
         }
     }
 }
 
-// The winner among a pending sentence's slots (greatest score, lowest candidate number among equals = the
-// reference's strict '>' in candidate order, :159); a slot that could not decide sends the sentence to the fallback.
+// The winner among a pending sentence's slots: the greatest score, if it beats every other candidate's by more than the
+// margin (then the reference's comparison of its own rounded sums, strict '>' in candidate order :159, picks the same
+// one); a slot that could not decide, or two candidates within the margin, send the sentence to the fallback.
 __global__ void mst_fast_pick_kernel(MstArgs a) {
     const int b = blockIdx.x, tid = threadIdx.x, L = a.L, R = a.cslots;
     if (a.status[b] == PHONLP_MST_FALLBACK) {  // phase 1 gave the sentence up: list it (reason in cand_n)
@@ -847,14 +864,19 @@ __global__ void mst_fast_pick_kernel(MstArgs a) {
     int l = a.sentlens[b];
     if (l > L) l = L;
     const int ns = a.cand_n[b] < R ? a.cand_n[b] : R;
-    double best = NEG_INF_D;
-    int bs = -1, bi = INT_MAX, bad = 0;
+    const double tau = a.tau[b];
+    double best = NEG_INF_D, second = NEG_INF_D;
+    int bs = -1, bad = 0;
     for (int s = 0; s < ns; ++s) {
         const double sc = a.cs_score[(long)b * R + s];
         const int ix = a.cs_idx[(long)b * R + s];
         if (ix < 0) bad = 1;
-        else if (sc > best || (sc == best && ix < bi)) { best = sc; bs = s; bi = ix; }
+        else {
+            second = sc > best ? best : (sc > second ? sc : second);
+            if (sc > best) { best = sc; bs = s; }
+        }
     }
+    if (best - second <= tau) bad = 1;  // two candidates within the margin: the reference's order decides (strict '>', :159)
     if (bad || bs < 0) {
         if (tid == 0) {
             a.status[b] = PHONLP_MST_FALLBACK;
@@ -875,7 +897,7 @@ int launch_mst_fast_pick(MstArgs a, hipStream_t stream) {  // for mst_round.hip,
 static size_t fast_hist_stride(int L) { return (size_t)(L + 1) * 3 * ((L + 3) & ~3); }
 size_t mst_fast_bytes(int B, int L) {
     const size_t q = (size_t)B * kFastSlots;
-    return align_up((size_t)B * sizeof(int32_t), 256) + align_up(q * sizeof(double), 256) +
+    return align_up((size_t)B * sizeof(int32_t), 256) + align_up((size_t)B * sizeof(double), 256) + align_up(q * sizeof(double), 256) +
            align_up(q * sizeof(int32_t), 256) + align_up(q * L * sizeof(uint16_t), 256) +
            align_up(q * fast_hist_stride(L), 256);
 }
@@ -883,6 +905,7 @@ void mst_fast_carve(MstArgs &a, void *base) {
     char *p = (char *)base;
     const size_t q = (size_t)a.B * kFastSlots;
     a.fb_list = (int32_t *)p;  p += align_up((size_t)a.B * sizeof(int32_t), 256);
+    a.tau = (double *)p;       p += align_up((size_t)a.B * sizeof(double), 256);
     a.cs_score = (double *)p;  p += align_up(q * sizeof(double), 256);
     a.cs_idx = (int32_t *)p;   p += align_up(q * sizeof(int32_t), 256);
     a.cs_tree = (uint16_t *)p; p += align_up(q * a.L * sizeof(uint16_t), 256);

@@ -1,7 +1,8 @@
 // Chu-Liu-Edmonds single-root MST, round-based decode for sentences too long for LDS (128 < L <= 1024).
 //
-// Same algorithm and the same two conditions as mst_fast.hip -- (G) exact float64 sums, (U) every selection strictly
-// unique, under which the maximum arborescence is unique and equals the reference's (models/common/chuliu_edmonds.py:52-169;
+// Same algorithm and the same condition as mst_fast.hip -- (M): every selection beats every other option by more than
+// the margin tau = mst_margin(l, max|entry|), under which the maximum arborescence is unique by a margin the
+// reference's float64 rounding cannot bridge, so the reference returns it too (models/common/chuliu_edmonds.py:52-169;
 // the argument is in mst_fast.hip's header) -- in the form that suits a matrix that does not fit a CU's LDS:
 //
 //  * the matrix is never rewritten and never copied: rows are read from the arc log-probabilities in global memory
@@ -12,8 +13,8 @@
 //    component are rescanned (a wavefront per row, four rows' loads in flight), and a new component's in-edge is the
 //    best of its rows' (best_v + off);
 //  * the whole workgroup (one thread per word) runs a round: pointer doubling on packed (smallest index, pointer) words
-//    finds the cycles and their labels, LDS atomics (exact sums, so their order is free) the cycle totals and the
-//    components' arg-max;
+//    finds the cycles and their labels, LDS atomics the cycle totals (their order of addition moves a total by a few
+//    ulps, far inside the margin every comparison is held to) and the components' arg-max;
 //  * the expansion record of a round (component and in-edge of every word before the merge, 3 x u16 per word) goes to
 //    the workgroup's region of the caller's workspace (the expansion stack of mst.hip's kernel, which only runs
 //    afterwards, for the sentences this decode could not prove itself on).
@@ -47,28 +48,29 @@ template <int CTRL>
 __device__ __forceinline__ int rdpp_i(int v) {
     return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false);
 }
-// (value, index, duplicate) arg-max step: greatest value; `dup` set when the maximum is not unique
-__device__ __forceinline__ void argmax_merge(float &bv, int &bj, int &dup, float v2, int j2, int d2) {
-    const bool gt = v2 > bv, eq = v2 == bv;
-    dup = gt ? d2 : (eq ? 1 : dup);
+// (value, index, near-duplicate) arg-max step: greatest value; `dup` set when the runner-up is within tau of it (the
+// bookkeeping of mst_fast.hip: a -inf operand gives a +inf or NaN difference, which compares false)
+__device__ __forceinline__ void argmax_merge(float &bv, int &bj, int &dup, float v2, int j2, int d2, float tau) {
+    const bool gt = v2 > bv;
+    const int near = ((gt ? v2 - bv : bv - v2) <= tau) ? 1 : 0;
+    dup = (gt ? d2 : dup) | near;
     bj = gt ? j2 : bj;
     bv = gt ? v2 : bv;
 }
 template <int CTRL>
-__device__ __forceinline__ void argmax_dpp(float &bv, int &bj, int &dup) {
-    argmax_merge(bv, bj, dup, __int_as_float(rdpp_i<CTRL>(__float_as_int(bv))), rdpp_i<CTRL>(bj), rdpp_i<CTRL>(dup));
+__device__ __forceinline__ void argmax_dpp(float &bv, int &bj, int &dup, float tau) {
+    argmax_merge(bv, bj, dup, __int_as_float(rdpp_i<CTRL>(__float_as_int(bv))), rdpp_i<CTRL>(bj), rdpp_i<CTRL>(dup), tau);
 }
 
 // Best column of up to four rows among the columns outside each row's component (and not column 0 when `skip0`), by one
 // wavefront: lanes over columns, the loads of CG 64-column chunks of the four rows issued before their first
 // comparison (a rolled loop over the groups keeps the kernel inside its 128 registers).  Columns past the row's end are
-// read at the clamped column L - 1 (always inside the matrix) and masked.  CHECK: the exactness scan (G) of the rows'
-// entries on the side.  Lane 0 stores best_j / best_v; a tied or empty row raises sc[RS_FAIL].
+// read at the clamped column L - 1 (always inside the matrix) and masked.  Lane 0 stores best_j / best_v; a row whose
+// maximum does not lead by more than tau, or an empty row, raises sc[RS_FAIL].
 // (`dup` is an int on purpose: as a bool the four-row unrolled form sends the compiler into a minutes-long search.)
-template <bool CHECK, int NCH, int CG>
+template <int NCH, int CG>
 __device__ __forceinline__ void scan_rows4(const float *arc, int L, int l, const int *comp, const int (&rows)[4], int nrows,
-                                           bool skip0, int root, int lane, int *bestJ, float *bestV, int *sc, int &glo,
-                                           int &ghi, int &gbad) {
+                                           bool skip0, int root, int lane, int *bestJ, float *bestV, int *sc, float tau) {
     const float NEGF = -__builtin_inff();
     float bv[4];
     int bj[4], ci[4], ri[4], dup[4];
@@ -98,24 +100,11 @@ __device__ __forceinline__ void scan_rows4(const float *arc, int L, int l, const
             const bool colok = j < l && !(skip0 && j == 0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                if (CHECK) {  // selects only
-                    const unsigned bits = __float_as_uint(val[c][r]);
-                    const int e = (bits >> 23) & 0xFF;
-                    const unsigned man = bits & 0x7FFFFFu;
-                    const bool live = j < l && j != ri[r];
-                    // NaN, +inf (-inf = no edge) and denormals (zero is on every grid) are off the grid
-                    const bool bad = live && ((e == 255 && (man != 0 || !(bits >> 31))) || (e == 0 && man != 0));
-                    const bool norm = live && e != 255 && e != 0;
-                    const int tz = __builtin_ctz(man | 0x800000u);
-                    const int elo = e - 150 + tz, ehi = e - 126;
-                    gbad |= bad ? 1 : 0;
-                    glo = (norm && elo < glo) ? elo : glo;
-                    ghi = (norm && ehi > ghi) ? ehi : ghi;
-                }
                 const bool ok = colok && cj[c] != ci[r];
                 const float v = ok ? val[c][r] : NEGF;
-                const bool gt = v > bv[r], eq = ok && v == bv[r];
-                dup[r] = gt ? 0 : (dup[r] | (eq ? 1 : 0));
+                const bool gt = v > bv[r];
+                const int near = (ok && (gt ? v - bv[r] : bv[r] - v) <= tau) ? 1 : 0;
+                dup[r] = gt ? near : (dup[r] | near);
                 bj[r] = gt ? j : bj[r];
                 bv[r] = gt ? v : bv[r];
             }
@@ -124,13 +113,13 @@ __device__ __forceinline__ void scan_rows4(const float *arc, int L, int l, const
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         int d = dup[r];
-        argmax_dpp<0xB1>(bv[r], bj[r], d);    // quad_perm xor 1
-        argmax_dpp<0x4E>(bv[r], bj[r], d);    // quad_perm xor 2
-        argmax_dpp<0x141>(bv[r], bj[r], d);   // row_half_mirror
-        argmax_dpp<0x140>(bv[r], bj[r], d);   // row_mirror: every lane of a 16-lane row holds the row's result
+        argmax_dpp<0xB1>(bv[r], bj[r], d, tau);    // quad_perm xor 1
+        argmax_dpp<0x4E>(bv[r], bj[r], d, tau);    // quad_perm xor 2
+        argmax_dpp<0x141>(bv[r], bj[r], d, tau);   // row_half_mirror
+        argmax_dpp<0x140>(bv[r], bj[r], d, tau);   // row_mirror: every lane of a 16-lane row holds the row's result
 #pragma unroll
         for (int o = 16; o <= 32; o <<= 1)
-            argmax_merge(bv[r], bj[r], d, __shfl_xor(bv[r], o), __shfl_xor(bj[r], o), __shfl_xor(d, o));
+            argmax_merge(bv[r], bj[r], d, __shfl_xor(bv[r], o), __shfl_xor(bj[r], o), __shfl_xor(d, o), tau);
         if (r < nrows && lane == 0) {
             const int i = ri[r];
             if (i == root) { bv[r] = 0.f; bj[r] = 0; d = 0; }  // set_root: the row's only edge, weight 0 (:147-148)
@@ -193,44 +182,63 @@ __global__ __launch_bounds__(1024) void mst_round_kernel(MstArgs a) {
     const int v = tid;
     const bool node = v < l;
 
-    double best_score = NEG_INF_D;
+    // ---- the margin's scale (phase 1): the largest finite |entry| of the rows >= 1 off the diagonal, in one pass over
+    // the matrix (a few microseconds from L2); NaN or +inf anywhere: fallback
+    double tau;
+    if (mode == 1) {
+        if (tid == 0) { sc[RS_LO] = 0; sc[RS_BAD] = 0; }
+        __syncthreads();
+        unsigned amax = 0;
+        int bad = 0;
+        for (int i = 1 + wave; i < l; i += nw) {
+            const float *rp = arc + (long)i * L;
+            for (int j0 = 0; j0 < l; j0 += 256) {
+                float x[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { const int j = j0 + 64 * c + lane; x[c] = rp[j < L ? j : L - 1]; }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int j = j0 + 64 * c + lane;
+                    const unsigned bits = __float_as_uint(x[c]), mag = bits & 0x7FFFFFFFu;
+                    const bool live = j < l && j != i;
+                    if (live && mag >= 0x7F800000u) { if (mag != 0x7F800000u || !(bits >> 31)) bad = 1; }  // -inf = no edge
+                    else if (live) amax = mag > amax ? mag : amax;
+                }
+            }
+        }
+        if (amax) atomicMax(reinterpret_cast<unsigned *>(&sc[RS_LO]), amax);
+        if (bad) sc[RS_BAD] = 1;
+        __syncthreads();
+        if (sc[RS_BAD]) {  // block-uniform
+            if (tid == 0) {
+                a.status[b] = PHONLP_MST_FALLBACK;
+                a.cand_n[b] = 1;  // why (diagnostics; the pick kernel lists the sentence): 1 = NaN / +inf entries
+            }
+            return;
+        }
+        tau = mst_margin(l, __uint_as_float((unsigned)sc[RS_LO]));
+        if (tid == 0) a.tau[b] = tau;
+    } else {
+        tau = a.tau[b];
+    }
+    const float tauf = __double2float_ru(tau);
+
+    double best_score = NEG_INF_D, second_score = NEG_INF_D;
     int best_ci = -1, failed = 0;
     for (int ci = slot; ci < ncand; ci += CS) {  // phase 1: one trip; phase 2: this slot's candidates
         const int root = mode == 2 ? a.cand_root[(long)b * L + ci] : -1;
         const bool skip0 = root >= 1;
         __syncthreads();
-        if (tid == 0) { sc[RS_LO] = INT_MAX; sc[RS_HI] = INT_MIN; sc[RS_BAD] = 0; sc[RS_FAIL] = 0; }
+        if (tid == 0) sc[RS_FAIL] = 0;
         if (node) { comp[v] = v; off[v] = 0.0; selI[v] = v; mark[v] = 0; bestJ[v] = 0; bestV[v] = 0.f; }
         __syncthreads();
-        // ---- first arg-max of every row (ref :58) and, in phase 1, the exactness test (G)
-        {
-            int glo = INT_MAX, ghi = INT_MIN, gbad = 0;
-            for (int r0 = 1 + 4 * wave; r0 < l; r0 += 4 * nw) {
-                const int rows[4] = {r0, r0 + 1, r0 + 2, r0 + 3};
-                const int n = l - r0 < 4 ? l - r0 : 4;
-                if (mode == 1) scan_rows4<true, NCH, CG>(arc, L, l, comp, rows, n, skip0, root, lane, bestJ, bestV, sc, glo, ghi, gbad);
-                else scan_rows4<false, NCH, CG>(arc, L, l, comp, rows, n, skip0, root, lane, bestJ, bestV, sc, glo, ghi, gbad);
-            }
-            if (mode == 1) {
-                if (glo != INT_MAX) { atomicMin(&sc[RS_LO], glo); atomicMax(&sc[RS_HI], ghi); }
-                if (gbad) sc[RS_BAD] = 1;
-            }
+        // ---- first arg-max of every row (ref :58)
+        for (int r0 = 1 + 4 * wave; r0 < l; r0 += 4 * nw) {
+            const int rows[4] = {r0, r0 + 1, r0 + 2, r0 + 3};
+            const int n = l - r0 < 4 ? l - r0 : 4;
+            scan_rows4<NCH, CG>(arc, L, l, comp, rows, n, skip0, root, lane, bestJ, bestV, sc, tauf);
         }
         __syncthreads();
-        if (mode == 1) {
-            int nbits = 1;
-            while ((1 << (nbits - 1)) < l) ++nbits;  // ceil(log2 l) + 1
-            const int lo = sc[RS_LO], hi = sc[RS_HI];
-            const int q = lo < 0 ? -lo : 0;
-            const bool exact = !sc[RS_BAD] && (lo == INT_MAX || hi + q + nbits <= 52);
-            if (!exact) {  // block-uniform
-                if (tid == 0) {
-                    a.status[b] = PHONLP_MST_FALLBACK;
-                    a.cand_n[b] = 1;  // why (diagnostics; the pick kernel lists the sentence): 1 = (G)
-                }
-                return;
-            }
-        }
         if (node && v >= 1) { selJ[v] = bestJ[v]; selV[v] = (double)bestV[v]; }
         STAMP(0);
         RCOUNT(11, 1);
@@ -263,7 +271,7 @@ __global__ __launch_bounds__(1024) void mst_round_kernel(MstArgs a) {
             const bool oncyc = rep && mark[v] == stamp;
             if (oncyc) {
                 lab[v] = wf >> 16;
-                atomicAdd(&tot[wf >> 16], selV[v]);  // exact under (G): the order of the additions is free (:75)
+                atomicAdd(&tot[wf >> 16], selV[v]);  // (:75) the order moves the total by ulps: far inside the margin
             }
             if (node) {  // this round's record: components and in-edges BEFORE the merge
                 uint16_t *hr = hist + (long)rounds * 3 * L;
@@ -294,17 +302,17 @@ __global__ __launch_bounds__(1024) void mst_round_kernel(MstArgs a) {
             {
                 const int n = sc[RS_NLIST];
                 RCOUNT(9, n);
-                int glo = 0, ghi = 0, gbad = 0;
                 for (int k0 = 4 * wave; k0 < n; k0 += 4 * nw) {
                     const int m = n - k0 < 4 ? n - k0 : 4;
                     const int rows[4] = {list[k0], list[k0 + (m > 1 ? 1 : 0)], list[k0 + (m > 2 ? 2 : 0)],
                                          list[k0 + (m > 3 ? 3 : 0)]};
-                    scan_rows4<false, NCH, CG>(arc, L, l, comp, rows, m, skip0, root, lane, bestJ, bestV, sc, glo, ghi, gbad);
+                    scan_rows4<NCH, CG>(arc, L, l, comp, rows, m, skip0, root, lane, bestJ, bestV, sc, tauf);
                 }
             }
             __syncthreads();
             STAMP(5);
-            // ---- the new components' in-edges: strictly best row (:88-97 in one step)
+            // ---- the new components' in-edges: the best row (:88-97 in one step), which must lead every other row of the
+            // component by more than tau
             unsigned long long key = 0ull;
             double val = 0.0;
             if (merged) {
@@ -314,10 +322,14 @@ __global__ __launch_bounds__(1024) void mst_round_kernel(MstArgs a) {
             }
             __syncthreads();
             if (merged && key == ckey[nc]) {
-                if (atomicAdd(&cnt[nc], 1) > 0) sc[RS_FAIL] = 1;  // two rows attain it: (U) fails
+                if (atomicAdd(&cnt[nc], 1) > 0) sc[RS_FAIL] = 1;  // two rows attain it
                 selI[nc] = v;
                 selJ[nc] = bestJ[v];
                 selV[nc] = val;
+            } else if (merged) {
+                const unsigned long long kb = ckey[nc];  // the winner's value back from its key
+                const double top = __longlong_as_double((long long)((kb >> 63) ? (kb & 0x7FFFFFFFFFFFFFFFull) : ~kb));
+                if (top - val <= tau) sc[RS_FAIL] = 1;  // a runner-up inside the margin
             }
             __syncthreads();
             fail_ = sc[RS_FAIL];
@@ -378,7 +390,7 @@ __global__ __launch_bounds__(1024) void mst_round_kernel(MstArgs a) {
                 if (tid == 0) { a.cand_n[b] = nroot; a.status[b] = PHONLP_MST_PENDING; }
             }
         } else {
-            // ---- a candidate's score (ref :155-158): exact, so the order of the additions is free
+            // ---- a candidate's score (ref :155-158); the order of the additions moves it by ulps, the pick allows for tau
             if (tid == 0) dsum[0] = (double)arc[(long)root * L];
             __syncthreads();
             double s = (node && v >= 1 && v != root) ? (double)arc[(long)v * L + head] : 0.0;
@@ -387,7 +399,8 @@ __global__ __launch_bounds__(1024) void mst_round_kernel(MstArgs a) {
             if (lane == 0) atomicAdd(&dsum[0], s);
             __syncthreads();
             const double total = dsum[0];
-            if (total > best_score) {  // strict: the first best candidate of this slot (ascending) wins
+            second_score = total > best_score ? best_score : (total > second_score ? total : second_score);
+            if (total > best_score) {  // the slot's best candidate; a runner-up within tau sends the sentence to the fallback
                 best_score = total;
                 best_ci = ci;
                 uint16_t *tr = a.cs_tree + ((long)b * CS + slot) * L;
@@ -403,25 +416,27 @@ __global__ __launch_bounds__(1024) void mst_round_kernel(MstArgs a) {
         if (mode == 1) {
             if (failed) {
                 a.status[b] = PHONLP_MST_FALLBACK;
-                a.cand_n[b] = 2;  // 2 = (U), unconstrained decode
+                a.cand_n[b] = 2;  // 2 = a selection inside the margin, unconstrained decode
             }
         } else {
             const long qx = (long)b * CS + slot;
+            if (best_score - second_score <= tau) failed = 1;
             a.cs_score[qx] = failed ? NEG_INF_D : best_score;
             a.cs_idx[qx] = failed ? -2 : best_ci;
         }
     }
 }
 
-// ctr [CT_COUNT] (zeroed per call), fb_list [B], cand_root [B][L]
+// ctr [CT_COUNT] (zeroed per call), fb_list [B], tau [B], cand_root [B][L]
 size_t mst_round_bytes(int B, int L) {
     return align_up((size_t)CT_COUNT * sizeof(int32_t), 256) + align_up((size_t)B * sizeof(int32_t), 256) +
-           align_up((size_t)B * L * sizeof(int32_t), 256);
+           align_up((size_t)B * sizeof(double), 256) + align_up((size_t)B * L * sizeof(int32_t), 256);
 }
 void mst_round_carve(MstArgs &a, void *base) {
     char *p = (char *)base;
     a.ctr = (int32_t *)p;        p += align_up((size_t)CT_COUNT * sizeof(int32_t), 256);
     a.fb_list = (int32_t *)p;    p += align_up((size_t)a.B * sizeof(int32_t), 256);
+    a.tau = (double *)p;         p += align_up((size_t)a.B * sizeof(double), 256);
     a.cand_root = (int32_t *)p;
 }
 

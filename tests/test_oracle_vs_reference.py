@@ -38,6 +38,25 @@ def test_mst_random_vs_reference():
         assert rc == 0 and got.tolist() == want, trial
 
 
+@pytest.mark.parametrize("kind", ["confident", "wide", "nearties"])
+def test_mst_hard_families_vs_reference(kind):
+    """The families the GPU decoders' equivalence gate is tested on (tests/mst_families.py): the oracle they are compared
+    with must itself follow the reference there -- scores of any dynamic range, exact ties next to one-ulp gaps."""
+    from tests.mst_families import make
+    sys.setrecursionlimit(20000)
+    cle = _load("chuliu_edmonds.py")
+    rng = np.random.default_rng({"confident": 21, "wide": 22, "nearties": 23}[kind])
+    for trial in range(120):
+        l = int(rng.integers(2, 70))
+        m = make(kind, l, rng)
+        with np.errstate(invalid="ignore"):  # -inf - -inf inside the reference's contraction
+            want = cle.chuliu_edmonds_one_root(m.copy()).tolist()
+        got, rc = C.mst_one_root(m)
+        assert rc == 0 and got.tolist() == want, (kind, trial)
+        if trial % 4 == 0:
+            assert O.chuliu_edmonds_one_root(m).tolist() == want, (kind, trial)
+
+
 def test_viterbi_random_vs_reference():
     crf = _load("crf.py")
     rng = np.random.default_rng(12)
