@@ -86,6 +86,14 @@ int phonlp_split_rows(const float *X, int ldx, int rows, int K, void *planes, fl
 int phonlp_linear_split(const void *Xp, const float *x_inv, const void *Wp, const float *w_inv, const float *bias,
                         float *Y, int ldy, int M, int N, int K, int relu, const int32_t *sentlens, int L,
                         const float *pad_bias, int kind, void *stream);
+/* The same layer (biaffine.py:83-85 W1/W2) with its result written AS A SPLIT IMAGE (Yp: M rows of 4*N bytes, N % 16 == 0;
+ * y_inv [M]) for the next engine-2 product, so that neither the fp32 result nor a split pass over it exist.  The row
+ * scales are fixed before the product from a bound on the row's entries: |y[m][n]| <= bound_c * max_k |x[m][k]| +
+ * bound_b with bound_c >= sqrt(K) * max_n ||W[n]||_2 and bound_b >= max |bias|, |pad value| (the caller derives both from
+ * the weights at load); max_k |x[m][k]| is read off x_inv. */
+int phonlp_linear_split_image(const void *Xp, const float *x_inv, const void *Wp, const float *w_inv, const float *bias,
+                              void *Yp, float *y_inv, int M, int N, int K, int relu, const int32_t *sentlens, int L,
+                              const float *pad_bias, float bound_c, float bound_b, int kind, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Weight packing (one-time, at load).  Device-to-device kernels.
@@ -177,6 +185,19 @@ size_t phonlp_biaffine_arc_scores_ws_bytes(int B, int L, int H, int n_scorers);
 int phonlp_biaffine_arc_scores(const float *XF, int B, int L, int H, int n_scorers, int use_lin, int use_dist,
                                const float *Wbt, float *arc_logp, float *raw_opt, void *ws, size_t ws_bytes,
                                void *stream);
+
+/* Engine 2, stages A and B of the arc scorers in ONE kernel (biaffine.py:21-37 per scorer, annotate_model.py:192-214),
+ * for sentences of up to 128 words and H + 1 <= 416: XFp / x_inv = the first-layer image phonlp_linear_split_image
+ * wrote with N = n_scorers * 2 * KC columns, KC = phonlp_arc_kc(H) (per scorer the segments relu(W1 x + b1) | 1 | 0..
+ * and relu(W2 x + b2) | 1 | 0.., KC columns each); Wbp / wb_inv = the split image of the packed bilinear weights with
+ * every scorer's rows AND columns zero-padded to KC ([n_scorers * KC, KC]).  rows_total = rows of the image.  Packed
+ * ragged batches: off [B] (first row of every sentence), sentlens [B], pad_row / pad_inv = the image row (and inverse
+ * scale) of a padded head, i.e. of what the first layer gives a zero hidden row; else all four NULL / 0.
+ * Same results as phonlp_biaffine_arc_scores on the fp32 features, to fp32 rounding. */
+int phonlp_arc_kc(int H);
+int phonlp_arc_scores_split(const void *XFp, const float *x_inv, int rows_total, int B, int L, int H, int n_scorers,
+                            int use_lin, int use_dist, const void *Wbp, const float *wb_inv, const int32_t *off,
+                            const int32_t *sentlens, const void *pad_row, float pad_inv, float *arc_logp, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Label scores -- annotate_model.py:190,215 (deprel DeepBiaffineScorer + .max(3)[1]):

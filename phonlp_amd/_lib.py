@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libphonlp_heads.so")
 
-_i, _z, _p = ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p
+_i, _z, _p, _f = ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_float
 
 # name -> (restype, argtypes); mirrors include/phonlp_heads.h declaration by declaration
 SIGNATURES = {
@@ -19,6 +19,9 @@ SIGNATURES = {
     "phonlp_split_bytes": (_z, [_i, _i]),
     "phonlp_split_rows": (_i, [_p, _i, _i, _i, _p, _p, _p]),
     "phonlp_linear_split": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p]),
+    "phonlp_linear_split_image": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _p, _f, _f, _i, _p]),
+    "phonlp_arc_kc": (_i, [_i]),
+    "phonlp_arc_scores_split": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p]),
     "phonlp_pack_scorer_linear": (_i, [_p, _p, _p, _p, _i, _i, _p, _p, _p]),
     "phonlp_pack_bilinear": (_i, [_p, _i, _i, _p, _p]),
     "phonlp_pos_head_ws_bytes": (_z, [_i, _i, _i, _i, _i, _i]),

@@ -71,7 +71,7 @@ int launch_split_rows2(const float *X, long ldx, int rows, void *planes, long pi
 int launch_linear_f16x3(const char *tag, const void *Xp, long pitch_x, const float *x_inv, const void *Wp, long pitch_w,
                         const float *w_inv, const float *bias, float *Y, long ldy, int M, int N, int K16, int relu,
                         const int32_t *sentlens, int L, hipStream_t stream, const float *pad_bias, int rows4 = 0,
-                        const LinearArgs *at_heads = nullptr);
+                        const LinearArgs *at_heads = nullptr, const LinearArgs *image = nullptr);
 
 // One wavefront per token.  logits [M, U] (U <= 64) -> pos_pred, feat = [enc | softmax(logits) . emb].
 // ref annotate_model.py:138-146 / :177-183.  The row is assembled in this wave's LDS buffer; from there it goes out as

@@ -32,7 +32,29 @@ struct LinearArgs {
     int gm;   // linear_f16x3.hip: row tiles per group of the tile walk (0 = 4)
     int *tile_ctr;  // mode 2, persistent wide kernel: eight tile counters (one per XCD chunk of the walk), zero at launch
     int dbg;  // -DPHONLP_ABLATION builds only (PHONLP_X3_ABLATION): 1 = epilogue without its global stores, 2 = no epilogue
+    // linear_f16x3.hip, image output (img != NULL, Y unused): the layer's result is written as the SPLIT IMAGE the next
+    // engine-2 product reads (row pitch img_pitch bytes, N % 8 == 0 columns: h[8] l[8] per group of eight), scaled per
+    // row by a power of two chosen BEFORE the product from a bound on the row's entries,
+    //     |y[m][n]| <= img_c * max_k|x[m][k]| + img_b,  img_c >= sqrt(K) max_n ||W[n]||_2  (Cauchy-Schwarz),  img_b >= max|bias|,
+    // with max_k|x[m][k]| < 2^15 row_scale[m] read off the input image's own scale.  img_inv[m] = the inverse scale.  A
+    // bound instead of the row's true maximum costs nothing in accuracy until it is ~2^10 too large (f16 pieces keep 22
+    // bits of every element within 2^-(17 - log2 looseness) of the row's maximum; smaller ones are off by < 2^-39 of
+    // the bound) and saves the separate split pass over the result (8 bytes per element read + written).
+    unsigned char *img;
+    long img_pitch;
+    float *img_inv;
+    float img_c, img_b;
 };
+
+typedef _Float16 img_f16x4 __attribute__((ext_vector_type(4)));
+
+// scale (a power of two) that maps |y| <= U into f16's range with the bound just below 2^15, and its inverse
+__device__ __forceinline__ void image_scale_of_bound(float U, float &scale, float &inv) {
+    int e = (int)((__float_as_uint(U) >> 23) & 0xFF);  // biased exponent: U < 2^(e - 126)
+    e = e < 16 ? 16 : (e > 254 ? 254 : e);
+    scale = __uint_as_float((unsigned)(268 - e) << 23);
+    inv = __uint_as_float((unsigned)(e - 14) << 23);
+}
 
 // Epilogue shared by the dense-layer kernels: the wave's accumulators are transposed through a per-wave LDS
 // patch (32 rows x (TN*32 + 4) floats at lds + wave * 32 * EP; the caller guarantees WM*WN such patches fit and
@@ -114,6 +136,22 @@ __device__ __forceinline__ void linear_epilogue(f32x16 (&acc)[TM][TN], float *ld
 #ifdef PHONLP_ABLATION
                     if (a.dbg == 1 && v.x != 1234.5f) continue;
 #endif
+                    if (a.img) {  // the result as a split image (a.N % 8 == 0: the four columns are inside the row)
+                        float sc, inv;
+                        image_scale_of_bound(a.img_c * a.row_scale[row] * 32768.f + a.img_b, sc, inv);
+                        const float s4[4] = {v.x * sc, v.y * sc, v.z * sc, v.w * sc};  // exact (powers of two)
+                        img_f16x4 h, l;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            h[e] = (_Float16)s4[e];
+                            l[e] = (_Float16)(s4[e] - (float)h[e]);
+                        }
+                        unsigned char *o = a.img + (long)row * a.img_pitch + (col >> 3) * 32 + (col & 7) * 2;
+                        *reinterpret_cast<img_f16x4 *>(o) = h;
+                        *reinterpret_cast<img_f16x4 *>(o + 16) = l;
+                        if (col == 0) a.img_inv[row] = inv;
+                        continue;
+                    }
                     float *y = a.Y + (long)row * a.ldy + col;
                     if (vec_ok) {
                         *reinterpret_cast<float4 *>(y) = v;

@@ -1063,9 +1063,12 @@ __global__ __launch_bounds__(512, 1) void linear_f16x3_wide_heads_kernel(LinearA
 int launch_linear_f16x3(const char *tag, const void *Xp, long pitch_x, const float *x_inv, const void *Wp, long pitch_w,
                         const float *w_inv, const float *bias, float *Y, long ldy, int M, int N, int K16, int relu,
                         const int32_t *sentlens, int L, hipStream_t stream, const float *pad_bias, int rows4 = 0,
-                        const LinearArgs *at_heads = nullptr) {
-    if (!Xp || !Wp || !x_inv || !w_inv || (!Y && !at_heads) || M <= 0 || N <= 0 || K16 <= 0)
+                        const LinearArgs *at_heads = nullptr, const LinearArgs *image = nullptr) {
+    if (!Xp || !Wp || !x_inv || !w_inv || (!Y && !at_heads && !image) || M <= 0 || N <= 0 || K16 <= 0)
         return fail(PHONLP_ERR_SHAPE, "linear_split: bad argument");
+    if (image && (!image->img || !image->img_inv || (N & 7) || (image->img_pitch & 15) || image->img_pitch < 4L * N ||
+                  ((uintptr_t)image->img & 15) || rows4 || at_heads || !(image->img_c >= 0.f) || !(image->img_b >= 0.f)))
+        return fail(PHONLP_ERR_SHAPE, "linear_split: image output needs N %% 8 == 0, a 16-byte aligned image and its bound");
     if ((K16 & 15) || (pitch_x & 15) || (pitch_w & 15) || pitch_x < 4L * K16 || pitch_w < 4L * K16 ||
         ((uintptr_t)Xp & 15) || ((uintptr_t)Wp & 15))
         return fail(PHONLP_ERR_SHAPE, "linear_split: split images must be 16-byte aligned with K16 %% 16 == 0");
@@ -1094,6 +1097,10 @@ int launch_linear_f16x3(const char *tag, const void *Xp, long pitch_x, const flo
     a.dbg = abl;
 #endif
     a.rows4 = rows4;
+    if (image) {
+        a.img = image->img; a.img_pitch = image->img_pitch; a.img_inv = image->img_inv;
+        a.img_c = image->img_c; a.img_b = image->img_b;
+    }
     if (at_heads) {
         a.rows4 = 2;
         a.x2 = at_heads->x2; a.P = at_heads->P; a.ldx2 = at_heads->ldx2;
@@ -1225,6 +1232,22 @@ extern "C" int phonlp_linear_split(const void *Xp, const float *x_inv, const voi
     if (kind < 0 || kind > 3) return fail(PHONLP_ERR_SHAPE, "linear_split: kind must be 0..3");
     return launch_linear_f16x3(tags[kind], Xp, 4L * K16, x_inv, Wp, 4L * K16, w_inv, bias, Y, ldy, M, N, K16, relu, sentlens,
                                L, as_stream(stream), pad_bias);
+}
+
+// the same layer with its result written as the split image the next engine-2 product reads (LinearArgs::img)
+extern "C" int phonlp_linear_split_image(const void *Xp, const float *x_inv, const void *Wp, const float *w_inv,
+                                         const float *bias, void *Yp, float *y_inv, int M, int N, int K, int relu,
+                                         const int32_t *sentlens, int L, const float *pad_bias, float bound_c,
+                                         float bound_b, int kind, void *stream) {
+    if (K <= 0 || !Yp || !y_inv) return fail(PHONLP_ERR_SHAPE, "linear_split_image: bad argument");
+    if (N & 15) return fail(PHONLP_ERR_SHAPE, "linear_split_image: N must be a multiple of 16 (the image's k16 stages)");
+    const int K16 = (K + 15) / 16 * 16;
+    static const char *tags[] = {"linear_split", "linear:label_stage_a", "linear:label_w12", "linear:arc_w12"};
+    if (kind < 0 || kind > 3) return fail(PHONLP_ERR_SHAPE, "linear_split_image: kind must be 0..3");
+    LinearArgs im{};
+    im.img = (unsigned char *)Yp; im.img_pitch = 4L * N; im.img_inv = y_inv; im.img_c = bound_c; im.img_b = bound_b;
+    return launch_linear_f16x3(tags[kind], Xp, 4L * K16, x_inv, Wp, 4L * K16, w_inv, bias, nullptr, 0, M, N, K16, relu,
+                               sentlens, L, as_stream(stream), pad_bias, 0, nullptr, &im);
 }
 
 extern "C" size_t phonlp_label_t4_bytes(int B, int L, int H, int O) {

@@ -67,6 +67,17 @@ class HeadWeights:
     arc_W12p_s: Optional[tuple] = None
     lab_W12p_s: Optional[tuple] = None
     emb_eye: Optional[torch.Tensor] = None
+    # fused arc stages on engine 2 (ops.arc_scores_split): the first layer's weights with every half-segment padded to
+    # KC rows (its result is written as the image the arc kernel reads), the bound that fixes that image's row scales
+    # (include/phonlp_heads.h phonlp_linear_split_image), the bilinear weights padded to KC x KC per scorer, and the image
+    # row of a padded head.  None when H + 1 > 416.
+    arc_KC: int = 0
+    arc_W12q_s: Optional[tuple] = None
+    arc_b12q: Optional[torch.Tensor] = None
+    arc_b12q_pad: Optional[torch.Tensor] = None
+    arc_bound: Optional[tuple] = None
+    arc_Wbq_s: Optional[tuple] = None
+    arc_pad_img: Optional[tuple] = None  # (planes [1, S*2*KC*4], inverse scale as a float)
 
     @classmethod
     def from_state_dict(cls, sd: Dict[str, torch.Tensor], device="cuda", linearization=True, distance=True):
@@ -145,6 +156,7 @@ class HeadWeights:
         lab = pack("deprel")
         labf = pack_folded("deprel")
         labp = pack_folded_p("deprel")
+        fused_arc = cls._fused_arc_pack(arcp, arcf[1], arc[1], arc[2], H, n_arc)
         return cls(
             upos_hid_w=g("upos_hid.weight"), upos_hid_b=g("upos_hid.bias"),
             upos_clf_w=g("upos_clf.weight"), upos_clf_b=g("upos_clf.bias"),
@@ -165,7 +177,35 @@ class HeadWeights:
             lab_ones_col=lab[2][:, H].contiguous(),
             arc_W12p_s=tuple(ops.split_rows(arcp)), lab_W12p_s=tuple(ops.split_rows(labp)),
             emb_eye=torch.eye(U_, Up, dtype=torch.float32, device=device).contiguous(),
+            **fused_arc,
         )
+
+    @staticmethod
+    def _fused_arc_pack(W12p: torch.Tensor, b12f: torch.Tensor, b12: torch.Tensor, Wbt: torch.Tensor, H: int, S: int):
+        """W12p [S*2*KP, K] (first layer on [enc | tag probabilities]), its bias b12f and the unfolded bias b12 (what a
+        padded hidden row sees), Wbt [S*KP, KP] -> the operands of ops.linear_split_image / ops.arc_scores_split."""
+        KP, KC = ops.kp(H), ops.arc_kc(H)
+        if KC == 0:
+            return {}
+        dev, K = W12p.device, W12p.shape[1]
+
+        def pad_rows(t, rows_per_seg):  # [n_seg * KP, ...] -> [n_seg * KC, ...] with zero rows
+            n_seg = t.shape[0] // KP
+            out = torch.zeros((n_seg, KC) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
+            out[:, :KP] = t.view((n_seg, KP) + tuple(t.shape[1:]))
+            return out.view((n_seg * KC,) + tuple(t.shape[1:])).contiguous()
+
+        W12q, b12q, b12q_pad = pad_rows(W12p, KP), pad_rows(b12f, KP), pad_rows(b12, KP)
+        # |y[m][n]| <= ||x[m]||_2 ||W[n]||_2 + |b[n]| <= sqrt(K) max|x[m]| max_n ||W[n]||_2 + max|b|; 1 % of slack for
+        # the fp32 roundings of the product itself
+        bound_c = 1.01 * float(K) ** 0.5 * float(W12q.double().norm(dim=1).max())
+        bound_b = 1.01 * max(float(b12q.abs().max()), float(b12q_pad.abs().max())) + 1e-30
+        Wbq = torch.zeros((S, KC, KC), dtype=torch.float32, device=dev)
+        Wbq[:, :KP, :KP] = Wbt.view(S, KP, KP)
+        pad_planes, pad_inv = ops.split_rows(torch.relu(b12q_pad).view(1, -1).contiguous())
+        return dict(arc_KC=KC, arc_W12q_s=tuple(ops.split_rows(W12q)), arc_b12q=b12q, arc_b12q_pad=b12q_pad,
+                    arc_bound=(bound_c, bound_b), arc_Wbq_s=tuple(ops.split_rows(Wbq.view(S * KC, KC))),
+                    arc_pad_img=(pad_planes, float(pad_inv.item())))
 
     @staticmethod
     def _pad_relations(Wbt: torch.Tensor, H: int, O: int) -> torch.Tensor:
@@ -203,6 +243,9 @@ class TaskHeads:
             # joined fused form: 1 = the MST continues the main stream's queue behind the arc scores and the label
             # scorer's first layers go to a side stream (0: the MST on a side stream, the label layers on main)
             "mst_on_main": env("PHONLP_MST_ON_MAIN", "1") == "1",
+            # engine 2, sentences of up to 128 words: the arc scorers' stages A and B in one kernel, fed by the image the
+            # W1/W2 layer writes (0: stage A as a GEMM of its own, stage B converting fp32 operands: the round-2 form)
+            "arc_fused": env("PHONLP_ARC_FUSED", "1") == "1",
         }
         self._side = None
         # what the arc scorers' first layer gives a padded word (zero hidden row): relu of the layer's own bias
@@ -562,6 +605,9 @@ class TaskHeads:
                 # the embedding is folded into the scorers' weights: the "feat" image is [enc | tag probabilities]
                 emb, arcW, labW = w.emb_eye, w.arc_W12p_s, w.lab_W12p_s
                 D = enc_dep.shape[2] + emb.shape[1]
+            # the arc scorers' two bilinear stages as ONE kernel on the image their first layer writes (csrc/arc_f16x3.hip)
+            arc_fused = (cfg["arc_fused"] and w.arc_W12q_s is not None and Ld <= 128 and cfg["pos_fold"]
+                         and w.arc_W12p_s is not None)
             if pack:
                 # Live words only from here to the labels (the reference's dense layers run on PackedSequence data,
                 # annotate_model.py:155-187): every row-wise op sees ONE sentence of m_live words; the arc kernel and
@@ -571,16 +617,29 @@ class TaskHeads:
                 encp = ops.pack_rows(enc_dep.reshape(B * Ld, -1), map_d)
                 featp, feati, _, _, _ = ops.pos_head_split(encp.view(1, pack[0], -1), one_d, w.upos_hid_w, w.upos_hid_b,
                                                            w.upos_clf_w, w.upos_clf_b, emb, False)
-                XFa = ops.linear_split(featp, feati, arcW[0], arcW[1], w.arc_b12f, D, True, None, 0, None, 3)
-                arc_logp = ops.biaffine_arc_scores_packed(XFa, off_d, lens_d, self._arc_pad_row, B, Ld, w.arc_Wbt, w.H,
-                                                          w.n_arc_scorers, w.linearization, w.distance)
+                if arc_fused:
+                    xfp, xfi = ops.linear_split_image(featp, feati, w.arc_W12q_s[0], w.arc_W12q_s[1], w.arc_b12q, D, True,
+                                                      None, 0, None, w.arc_bound[0], w.arc_bound[1], 3)
+                    arc_logp = ops.arc_scores_split(xfp, xfi, B, Ld, w.H, w.n_arc_scorers, w.linearization, w.distance,
+                                                    w.arc_Wbq_s[0], w.arc_Wbq_s[1], off_d, lens_d, w.arc_pad_img[0],
+                                                    w.arc_pad_img[1])
+                else:
+                    XFa = ops.linear_split(featp, feati, arcW[0], arcW[1], w.arc_b12f, D, True, None, 0, None, 3)
+                    arc_logp = ops.biaffine_arc_scores_packed(XFa, off_d, lens_d, self._arc_pad_row, B, Ld, w.arc_Wbt, w.H,
+                                                              w.n_arc_scorers, w.linearization, w.distance)
             else:
                 featp, feati, _, _, _ = ops.pos_head_split(enc_dep.contiguous(), lens_d, w.upos_hid_w, w.upos_hid_b,
                                                            w.upos_clf_w, w.upos_clf_b, emb, False)
-                XFa = ops.linear_split(featp, feati, arcW[0], arcW[1], w.arc_b12f, D, True, lens_d, Ld,
-                                       w.arc_b12, 3)
-                arc_logp = ops.biaffine_arc_scores(XFa, B, Ld, w.arc_Wbt, w.H, w.n_arc_scorers, w.linearization,
-                                                   w.distance)
+                if arc_fused:
+                    xfp, xfi = ops.linear_split_image(featp, feati, w.arc_W12q_s[0], w.arc_W12q_s[1], w.arc_b12q, D, True,
+                                                      lens_d, Ld, w.arc_b12q_pad, w.arc_bound[0], w.arc_bound[1], 3)
+                    arc_logp = ops.arc_scores_split(xfp, xfi, B, Ld, w.H, w.n_arc_scorers, w.linearization, w.distance,
+                                                    w.arc_Wbq_s[0], w.arc_Wbq_s[1], None, None, None, 0.0)
+                else:
+                    XFa = ops.linear_split(featp, feati, arcW[0], arcW[1], w.arc_b12f, D, True, lens_d, Ld,
+                                           w.arc_b12, 3)
+                    arc_logp = ops.biaffine_arc_scores(XFa, B, Ld, w.arc_Wbt, w.H, w.n_arc_scorers, w.linearization,
+                                                       w.distance)
         else:
             feat, _, _ = ops.pos_head(enc_dep.contiguous(), lens_d, w.upos_hid_w, w.upos_hid_b, w.upos_clf_w,
                                       w.upos_clf_b, w.emb_dep)

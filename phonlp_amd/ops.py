@@ -630,6 +630,64 @@ def linear_split(xp: Tensor, x_inv: Tensor, wp: Tensor, w_inv: Tensor, bias: Opt
     return y
 
 
+def arc_kc(H: int) -> int:
+    """Columns per segment of the first-layer image the fused arc kernel reads (0: H + 1 > 416, not supported)."""
+    return int(lib().phonlp_arc_kc(int(H)))
+
+
+@torch.library.custom_op("phonlp_amd::linear_split_image", mutates_args=())
+def linear_split_image(xp: Tensor, x_inv: Tensor, wp: Tensor, w_inv: Tensor, bias: Optional[Tensor], K: int, relu: bool,
+                       sentlens: Optional[Tensor], L: int, pad_bias: Optional[Tensor], bound_c: float, bound_b: float,
+                       kind: int) -> Tuple[Tensor, Tensor]:
+    """linear_split with the result written as a split image (uint8 [M, 4*N], N % 16 == 0) + its inverse row scales [M];
+    bound_c / bound_b: include/phonlp_heads.h phonlp_linear_split_image."""
+    _need(xp, torch.uint8, "xp")
+    _need(wp, torch.uint8, "wp")
+    _need(x_inv, torch.float32, "x_inv")
+    _need(w_inv, torch.float32, "w_inv")
+    M, N = xp.shape[0], wp.shape[0]
+    if xp.shape[1] != wp.shape[1] or xp.shape[1] != lib().phonlp_split_bytes(1, K) or N % 16:
+        raise ValueError("linear_split_image: split images do not match K, or N % 16 != 0")
+    y = torch.empty((M, 4 * N), dtype=torch.uint8, device=xp.device)
+    y_inv = torch.empty((M,), dtype=torch.float32, device=xp.device)
+    check(lib().phonlp_linear_split_image(_p(xp), _p(x_inv), _p(wp), _p(w_inv), _p(bias), _p(y), _p(y_inv), M, N, K,
+                                          int(relu), _p(sentlens), L, _p(pad_bias), float(bound_c), float(bound_b), kind,
+                                          _stream()), "phonlp_linear_split_image")
+    return y, y_inv
+
+
+@linear_split_image.register_fake
+def _(xp, x_inv, wp, w_inv, bias, K, relu, sentlens, L, pad_bias, bound_c, bound_b, kind):
+    return (torch.empty((xp.shape[0], 4 * wp.shape[0]), dtype=torch.uint8, device=xp.device),
+            torch.empty((xp.shape[0],), dtype=torch.float32, device=xp.device))
+
+
+@torch.library.custom_op("phonlp_amd::arc_scores_split", mutates_args=())
+def arc_scores_split(xfp: Tensor, xf_inv: Tensor, B: int, L: int, H: int, n_scorers: int, use_lin: bool, use_dist: bool,
+                     wbp: Tensor, wb_inv: Tensor, off: Optional[Tensor], sentlens: Optional[Tensor],
+                     pad_row: Optional[Tensor], pad_inv: float) -> Tensor:
+    """Engine 2: stages A and B of the arc scorers fused, from the first-layer IMAGE (linear_split_image) -> arc
+    log-probs [B,L,L].  Packed rows: off / sentlens / pad_row (image row) / pad_inv; padded dependents' rows are NOT
+    written.  include/phonlp_heads.h phonlp_arc_scores_split."""
+    _need(xfp, torch.uint8, "xfp")
+    _need(wbp, torch.uint8, "wbp")
+    _need(xf_inv, torch.float32, "xf_inv")
+    _need(wb_inv, torch.float32, "wb_inv")
+    KC = arc_kc(H)
+    if KC == 0 or xfp.shape[1] != n_scorers * 2 * KC * 4 or tuple(wbp.shape) != (n_scorers * KC, KC * 4):
+        raise ValueError("arc_scores_split: images do not match H / n_scorers")
+    out = torch.empty((B, L, L), dtype=torch.float32, device=xfp.device)
+    check(lib().phonlp_arc_scores_split(_p(xfp), _p(xf_inv), xfp.shape[0], B, L, H, n_scorers, int(use_lin), int(use_dist),
+                                        _p(wbp), _p(wb_inv), _p(off), _p(sentlens), _p(pad_row), float(pad_inv), _p(out),
+                                        _stream()), "phonlp_arc_scores_split")
+    return out
+
+
+@arc_scores_split.register_fake
+def _(xfp, xf_inv, B, L, H, n_scorers, use_lin, use_dist, wbp, wb_inv, off, sentlens, pad_row, pad_inv):
+    return torch.empty((B, L, L), dtype=torch.float32, device=xfp.device)
+
+
 @torch.library.custom_op("phonlp_amd::biaffine_arc_scores", mutates_args=())
 def biaffine_arc_scores(XF: Tensor, B: int, L: int, Wbt: Tensor, H: int, n_scorers: int, use_lin: bool,
                         use_dist: bool) -> Tensor:
