@@ -26,6 +26,8 @@
 // `pad` (what the first layer gives a zero hidden row); padded dependents are not scored.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "linear_args.h"
 
 namespace phonlp {
@@ -33,6 +35,19 @@ namespace phonlp {
 typedef _Float16 af16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 af16x4 __attribute__((ext_vector_type(4)));
 
+#ifndef ARC_PIN_MODE
+#define ARC_PIN_MODE 0
+#endif
+#ifndef ARC_NBUF
+#define ARC_NBUF 4
+#endif
+#if ARC_PIN_MODE == 1
+#define ARC_PIN(X) asm volatile("" : "+v"(X))
+#elif ARC_PIN_MODE == 2
+#define ARC_PIN(X) asm volatile("" : "+a"(X))
+#else
+#define ARC_PIN(X) do {} while (0)
+#endif
 #define ARC_MFMA(A, B, C) \
     __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(af16x8, A), __builtin_bit_cast(af16x8, B), C, 0, 0, 0)
 
@@ -52,37 +67,58 @@ struct ArcSplitArgs {
     const int32_t *off, *sentlens;  // packed rows (else NULL)
     const unsigned char *pad;       // packed: image row of a padded head
     float pad_inv;
+    long long *dbg;                 // diagnostic builds only (-DARC_STAMPS): cycle stamps of block 0
 };
 
-// logsigmoid / softplus exactly as torch defines them (F.logsigmoid; F.softplus beta=1, threshold=20).
-__device__ __forceinline__ float arcs_log_sigmoid(float x) { return fminf(x, 0.f) - log1pf(expf(-fabsf(x))); }
-__device__ __forceinline__ float arcs_softplus(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+#ifdef ARC_STAMPS
+#define ARC_STAMP(k) do { if (a.dbg && blockIdx.x == 0 && tid == 0) a.dbg[k] = clock64(); } while (0)
+#else
+#define ARC_STAMP(k) do {} while (0)
+#endif
+
+// logsigmoid / softplus as torch defines them (F.logsigmoid; F.softplus beta=1, threshold=20), on the hardware's exp2 / log2
+// (v_exp_f32 / v_log_f32, ~1 ulp each): one wavefront per SIMD has nothing to hide libm's expf / log1pf sequences
+// behind -- with them the three scorers' terms and the softmax were 40 % of this kernel.  log1p(u) = log(y) - ((y - 1) - u) / y
+// with y = fl(1 + u) keeps the accuracy of log1p for small u; absolute error of a term <= ~2e-7 (scores are O(1..10),
+// the parity bound on them is 1e-3 relative).
+__device__ __forceinline__ float arcs_log1p(float u) {
+    const float y = 1.f + u;
+    return __logf(y) - ((y - 1.f) - u) * __builtin_amdgcn_rcpf(y);
+}
+__device__ __forceinline__ float arcs_log_sigmoid(float x) { return fminf(x, 0.f) - arcs_log1p(__expf(-fabsf(x))); }
+__device__ __forceinline__ float arcs_softplus(float x) { return x > 20.f ? x : arcs_log1p(__expf(x)); }
 
 template <int NT>
 struct ArcSplitLayout {
     static constexpr int KC = 32 * NT;
-    static constexpr int NLA = 8 + 2 * NT;          // wave-loads (16 rows x 64 bytes) of a phase-A stage: X1, then Wb
-    static constexpr int NLW = (NLA + 3) / 4;       // per wavefront (the last ones may be dummies)
-    static constexpr int STAGE_A = NLW * 4 * 1024;
+    static constexpr int NTW = (NT + 1) / 2;        // phase A: tiles of 32 output features per wavefront (two halves)
+    static constexpr int NA = 2 * NTW;              // tiles computed (NT odd: the last one is a pad tile nobody uses)
+    static constexpr int NLA = 8 + 2 * NA;          // wave-loads (16 rows x 64 bytes) of a phase-A stage: X1, then Wb
+    static constexpr int NLW = (NLA + 7) / 8;       // per wavefront (the last ones may be dummies)
+    static constexpr int STAGE_A = NLW * 8 * 1024;
     static constexpr int SLAB_B = 2 * 128 * 64;     // phase B: a k32 chunk of the heads' X2, two k16 stages of 128 rows
-    static constexpr int RING_A = 3 * STAGE_A, RING_B = 3 * SLAB_B + 4 * 4096;
+    static_assert(true, "");
+    static constexpr int NSLAB = 5;                 // phase B: slabs in the ring (NSLAB - 1 in flight: they come from HBM / MALL)
+    static constexpr int RING_A = 3 * STAGE_A, RING_B = NSLAB * SLAB_B + 4 * 2 * 4096;  // B: the slabs + two patches per row tile
     static constexpr int RING = RING_A > RING_B ? RING_A : RING_B;
-    static constexpr int TOTAL = RING + 4 * 32 * 4 + KC * 4;  // + the waves' row factors + the scorer's weight-row scales
+    static constexpr int TOTAL = RING + (4 * 32 + 2 * 4 * 32 + NA * 32) * 4;  // + row factors, row maxima, weight-row scales
 };
 
 template <int NT>
-__global__ __launch_bounds__(256, 1) void arc_f16x3_kernel(ArcSplitArgs a) {
+__global__ __launch_bounds__(512, 1) void arc_f16x3_kernel(ArcSplitArgs a) {
     using Ly = ArcSplitLayout<NT>;
-    constexpr int KC = Ly::KC, NLW = Ly::NLW, STAGE_A = Ly::STAGE_A, SLAB_B = Ly::SLAB_B;
+    constexpr int KC = Ly::KC, NTW = Ly::NTW, NLW = Ly::NLW, STAGE_A = Ly::STAGE_A, SLAB_B = Ly::SLAB_B;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int mt = wave & 3, nh = wave >> 2;  // row tile (dependents 32 mt ..), half (phase A: output features; B: head columns)
     const int r = lane & 31, hh = lane >> 5;
     const int b = blockIdx.x, L = a.L;
     const int len = a.off ? min(max(a.sentlens[b], 0), L) : L;  // dependents scored; heads j < len are real rows
     const long rowbase = a.off ? a.off[b] : (long)b * L;
-    float *rowfac = reinterpret_cast<float *>(lds + Ly::RING) + wave * 32;
-    float *wscale = reinterpret_cast<float *>(lds + Ly::RING) + 4 * 32;  // wb_inv of the current scorer's KC rows
-    unsigned char *patch = lds + 3 * SLAB_B + wave * 4096;
+    float *rowfac = reinterpret_cast<float *>(lds + Ly::RING);  // [4][32]
+    float *rmax = rowfac + 4 * 32;                              // [2][4][32]
+    float *wscale = rmax + 2 * 4 * 32;                          // wb_inv of the current scorer's rows
+    unsigned char *patch = lds + Ly::NSLAB * SLAB_B + mt * 8192;  // the row tile's two Ta patches
 
     // fragment addressing inside a k16 stage image (rows of 64 bytes, chunk c of row R at slot c ^ ((R >> 2) & 3))
     const int sw = (r >> 2) & 3;
@@ -97,116 +133,153 @@ __global__ __launch_bounds__(256, 1) void arc_f16x3_kernel(ArcSplitArgs a) {
         return a.XF + row * a.pitch_x;
     };
 
-    float cell[4][16];  // the sum of the scorers' terms: rows acc_row(e, lane) of the wave's tile, column 32 jt + r
+    float gj[2];  // inverse scale of the heads' image rows (the X2 side) of the wave's two column tiles
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) cell[jt][e] = 0.f;
-    float gj[4];  // inverse scale of the heads' image rows (the X2 side)
-#pragma unroll
-    for (int jt = 0; jt < 4; ++jt) {
-        const int j = 32 * jt + r;
+    for (int k = 0; k < 2; ++k) {
+        const int j = 32 * (2 * nh + k) + r;
         long row = rowbase + j;
         row = row < a.rows_total ? row : a.rows_total - 1;
-        gj[jt] = (a.off && j >= len) ? a.pad_inv : a.x_inv[row];
+        gj[k] = (a.off && j >= len) ? a.pad_inv : a.x_inv[row];
     }
-    const float xi = a.x_inv[min(rowbase + 32 * wave + r, (long)a.rows_total - 1)];  // the lane's dependent
+    const float xi = a.x_inv[min(rowbase + 32 * mt + r, (long)a.rows_total - 1)];  // the lane's dependent
+    float *obase = a.out + ((long)b * L + 32 * mt) * L;
 
+    ARC_STAMP(0);
 #pragma unroll 1
     for (int s = 0; s < a.S; ++s) {
         // ------------------------------------------------------------------------------------------ phase A
         const unsigned char *srcA[NLW];
 #pragma unroll
         for (int q = 0; q < NLW; ++q) {
-            const int u = 4 * q + wave;
+            const int u = 8 * q + wave;
             if (u < 8) {
                 srcA[q] = xrow(16 * u + lr) + (long)(2 * s) * KC * 4 + chunk * 16;
             } else {
                 int n = 16 * (u - 8) + lr;
-                n = n < KC ? n : KC - 1;  // dummy wave-loads (they only keep the waves' load counts equal)
+                n = n < KC ? n : KC - 1;  // the pad tile's rows and dummy wave-loads: any valid row
                 srcA[q] = a.Wb + ((long)s * KC + n) * (KC * 4) + chunk * 16;
             }
         }
         auto issueA = [&](int st, int buf) {
 #pragma unroll
-            for (int q = 0; q < NLW; ++q) arc_dma16(srcA[q] + (long)st * 64, lds0 + (unsigned)(buf * STAGE_A + q * 4096));
+            for (int q = 0; q < NLW; ++q) arc_dma16(srcA[q] + (long)st * 64, lds0 + (unsigned)(buf * STAGE_A + q * 8192));
         };
-        f32x16 acc[NT];
+        f32x16 acc[NTW];
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NTW; ++t)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
         constexpr int nstA = KC / 16;
-        lds_barrier();  // everyone is done with the previous scorer's phase-B buffers (they alias this ring) and scales
-        for (int t = tid; t < KC; t += 256) wscale[t] = a.wb_inv[s * KC + t];  // published by phase A's barriers
+        __syncthreads();  // everyone is done with the previous scorer's phase-B buffers (they alias this ring) and scales
+        for (int t = tid; t < KC; t += 512) wscale[t] = a.wb_inv[s * KC + t];  // published by phase A's barriers
         issueA(0, 0);
         issueA(1, 1);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLW) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLW) : "memory");  // stage 0 landed
         __builtin_amdgcn_s_barrier();
-        int cur = 0;
-#pragma unroll 1
-        for (int st = 0; st < nstA; ++st) {
+        // A stage as pairs of tiles: the pair's six MFMAs (two accumulators alternating), the NEXT pair's fragment reads
+        // in front of them, the stage's LDS-DMA issues spread behind the pairs (an issue costs the wave 60-180 cycles; the
+        // SIMD's other wavefront computes meanwhile).
+        constexpr int NP = (NTW + 1) / 2;
+        auto stageA = [&](int st, int cur, auto issue) {
             const int nxt2 = cur == 0 ? 2 : cur - 1;  // (cur + 2) % 3: last read in iteration st - 1, behind that barrier
-            if (st + 2 < nstA) issueA(st + 2, nxt2);
             const unsigned char *buf = lds + cur * STAGE_A;
-            const u32x4 xh = *reinterpret_cast<const u32x4 *>(buf + (32 * wave + r) * 64 + off_h);
-            const u32x4 xl = *reinterpret_cast<const u32x4 *>(buf + (32 * wave + r) * 64 + off_l);
+            const unsigned char *wbuf = buf + 8192 + nh * (NTW * 2048);
+            const unsigned ld = lds0 + (unsigned)(nxt2 * STAGE_A);
+            const long so = (long)(st + 2) * 64;
+            const u32x4 xh = *reinterpret_cast<const u32x4 *>(buf + (32 * mt + r) * 64 + off_h);
+            const u32x4 xl = *reinterpret_cast<const u32x4 *>(buf + (32 * mt + r) * 64 + off_l);
+            u32x4 wh[2][2], wl[2][2];
+            auto read_pair = [&](int p, int slot) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const u32x4 wh = *reinterpret_cast<const u32x4 *>(buf + 8192 + (32 * t + r) * 64 + off_h);
-                const u32x4 wl = *reinterpret_cast<const u32x4 *>(buf + 8192 + (32 * t + r) * 64 + off_l);
-                acc[t] = ARC_MFMA(wl, xh, acc[t]);  // smallest terms first
-                acc[t] = ARC_MFMA(wh, xl, acc[t]);
-                acc[t] = ARC_MFMA(wh, xh, acc[t]);
+                for (int k = 0; k < 2; ++k) {
+                    const int t = 2 * p + k < NTW ? 2 * p + k : NTW - 1;
+                    wh[slot][k] = *reinterpret_cast<const u32x4 *>(wbuf + (32 * t + r) * 64 + off_h);
+                    wl[slot][k] = *reinterpret_cast<const u32x4 *>(wbuf + (32 * t + r) * 64 + off_l);
+                }
+            };
+            read_pair(0, 0);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const int sl = p & 1, t0 = 2 * p, t1 = 2 * p + 1;
+                if (p + 1 < NP) read_pair(p + 1, sl ^ 1);
+                acc[t0] = ARC_MFMA(wl[sl][0], xh, acc[t0]);  // smallest terms first
+                if (t1 < NTW) acc[t1] = ARC_MFMA(wl[sl][1], xh, acc[t1]);
+                acc[t0] = ARC_MFMA(wh[sl][0], xl, acc[t0]);
+                if (t1 < NTW) acc[t1] = ARC_MFMA(wh[sl][1], xl, acc[t1]);
+                acc[t0] = ARC_MFMA(wh[sl][0], xh, acc[t0]);
+                if (t1 < NTW) acc[t1] = ARC_MFMA(wh[sl][1], xh, acc[t1]);
+                ARC_PIN(acc[t0]);
+                if (t1 < NTW) ARC_PIN(acc[t1]);
+                if constexpr (decltype(issue)::value) {  // the stage's NLW issues spread evenly over its NP pairs
+#pragma unroll
+                    for (int q = p * NLW / NP; q < (p + 1) * NLW / NP; ++q) arc_dma16(srcA[q] + so, ld + q * 8192);
+                }
             }
-            if (st + 2 < nstA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLW) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+        int cur = 0, st = 0;
+#pragma unroll 1
+        for (; st + 2 < nstA; ++st) {
+            stageA(st, cur, std::true_type{});
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLW) : "memory");  // stage st + 1 has landed (st + 2 may be in flight)
             lds_barrier();
             cur = cur == 2 ? 0 : cur + 1;
         }
+#pragma unroll 1
+        for (; st < nstA; ++st) {
+            stageA(st, cur, std::false_type{});
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lds_barrier();
+            cur = cur == 2 ? 0 : cur + 1;
+        }
+        ARC_STAMP(1 + 4 * s);
         // ------------------------------------------------------------------------------------------ phase B
-        // the heads' X2 slabs: chunk c = two k16 stages of 128 rows, four wave-loads per wavefront
-        const unsigned char *srcB[4];
+        // the heads' X2 slabs: chunk c = two k16 stages of 128 rows, two wave-loads per wavefront
+        const unsigned char *srcB[2];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int u = 4 * q + wave;         // 0..15: stage u >> 3, rows 16 (u & 7) ..
+        for (int q = 0; q < 2; ++q) {
+            const int u = 8 * q + wave;         // 0..15: stage u >> 3, rows 16 (u & 7) ..
             const int j = 16 * (u & 7) + lr;
             const unsigned char *rowp = (a.off && j >= len && j < L) ? a.pad : xrow(j);
             srcB[q] = rowp + (long)(2 * s + 1) * KC * 4 + (u >> 3) * 64 + chunk * 16;
         }
         auto issueB = [&](int c, int buf) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) arc_dma16(srcB[q] + (long)c * 128, lds0 + (unsigned)(buf * SLAB_B + q * 4096));
+            for (int q = 0; q < 2; ++q) arc_dma16(srcB[q] + (long)c * 128, lds0 + (unsigned)(buf * SLAB_B + q * 8192));
         };
-        issueB(0, 0);
-        if (NT > 1) issueB(1, 1);
-        // Ta' = acc * wb_inv[n] (exact: powers of two); the row's maximum -> its power-of-two scale.  The weight rows'
-        // scales come from LDS, tile by tile, here and again at the conversion (hoisted global loads of all KC of them
-        // cost 200 registers)
+        constexpr int NSLAB = Ly::NSLAB, DB = NSLAB - 1;  // DB slabs ahead
+#pragma unroll
+        for (int c = 0; c < DB && c < NT; ++c) issueB(c, c);
+        // Ta' = acc * wb_inv[n] (exact: powers of two); the row's maximum over BOTH halves -> its power-of-two scale
         float amax = 0.f;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
+        for (int t = 0; t < NTW; ++t) {
+            if (nh * NTW + t < NT) {  // wave-uniform: not the pad tile
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 wi = *reinterpret_cast<const float4 *>(wscale + 32 * t + 8 * g + 4 * hh);
-                amax = fmaxf(amax, fmaxf(fmaxf(fabsf(acc[t][4 * g + 0] * wi.x), fabsf(acc[t][4 * g + 1] * wi.y)),
-                                         fmaxf(fabsf(acc[t][4 * g + 2] * wi.z), fabsf(acc[t][4 * g + 3] * wi.w))));
+                for (int g = 0; g < 4; ++g) {
+                    const float4 wi = *reinterpret_cast<const float4 *>(wscale + 32 * (nh * NTW + t) + 8 * g + 4 * hh);
+                    amax = fmaxf(amax, fmaxf(fmaxf(fabsf(acc[t][4 * g + 0] * wi.x), fabsf(acc[t][4 * g + 1] * wi.y)),
+                                             fmaxf(fabsf(acc[t][4 * g + 2] * wi.z), fabsf(acc[t][4 * g + 3] * wi.w))));
+                }
             }
         }
         amax = fmaxf(amax, __shfl_xor(amax, 32));
+        if (hh == 0) rmax[(nh * 4 + mt) * 32 + r] = amax;
+        lds_barrier();
+        amax = fmaxf(rmax[mt * 32 + r], rmax[(4 + mt) * 32 + r]);
         int E = (int)(__float_as_uint(amax) >> 23);
         E = E < 16 ? 16 : (E > 254 ? 254 : E);
         const float tscale = __uint_as_float((unsigned)(268 - E) << 23);  // maximum -> [2^14, 2^15)
         const float tinv = __uint_as_float((unsigned)(E - 14) << 23);
-        if (hh == 0) rowfac[r] = tinv * xi;
-        f32x16 acc2[4];
+        if (nh == 0 && hh == 0) rowfac[mt * 32 + r] = tinv * xi;
+        f32x16 acc2[2];
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt)
+        for (int k = 0; k < 2; ++k)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc2[jt][e] = 0.f;
-#pragma unroll
-        for (int c = 0; c < NT; ++c) {
-            // the chunk's pieces into the wave's patch: row r, stage g >> 1, eight bytes of chunk 2 (g & 1) (+1: low piece)
+            for (int e = 0; e < 16; ++e) acc2[k][e] = 0.f;
+        // a chunk's pieces into one of the row tile's two patches: row r, stage g >> 1, eight bytes of chunk 2 (g & 1) (+1: low
+        // piece); written by the wavefront that holds the chunk (tile t of its half)
+        auto convert = [&](int c, int t) {
+            unsigned char *pt = patch + (c & 1) * 4096;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 af16x4 h4, l4;
@@ -214,47 +287,84 @@ __global__ __launch_bounds__(256, 1) void arc_f16x3_kernel(ArcSplitArgs a) {
                 const float wi[4] = {wi4.x * tscale, wi4.y * tscale, wi4.z * tscale, wi4.w * tscale};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float v = acc[c][4 * g + e] * wi[e];
+                    const float v = acc[t][4 * g + e] * wi[e];
                     h4[e] = (_Float16)v;
                     l4[e] = (_Float16)(v - (float)h4[e]);
                 }
-                unsigned char *p = patch + (g >> 1) * 2048 + r * 64 + 8 * hh;
+                unsigned char *p = pt + (g >> 1) * 2048 + r * 64 + 8 * hh;
                 *reinterpret_cast<af16x4 *>(p + (((2 * (g & 1)) ^ sw) << 4)) = h4;
                 *reinterpret_cast<af16x4 *>(p + (((2 * (g & 1) + 1) ^ sw) << 4)) = l4;
             }
-            if (c + 1 < NT) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // slab c landed (c + 1 may be in flight)
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            lds_barrier();
-            if (c + 2 < NT) issueB(c + 2, (c + 2) % 3);
-            const unsigned char *slab = lds + (c % 3) * SLAB_B;
+        };
+        if (nh == 0) convert(0, 0);
+        ARC_STAMP(2 + 4 * s);
 #pragma unroll
-            for (int st = 0; st < 2; ++st) {
-                const u32x4 th = *reinterpret_cast<const u32x4 *>(patch + st * 2048 + r * 64 + off_h);
-                const u32x4 tl = *reinterpret_cast<const u32x4 *>(patch + st * 2048 + r * 64 + off_l);
-#pragma unroll
-                for (int jt = 0; jt < 4; ++jt) {  // all four column tiles whatever L is: branch-free (columns >= L are masked)
-                    const u32x4 qh = *reinterpret_cast<const u32x4 *>(slab + st * 8192 + (32 * jt + r) * 64 + off_h);
-                    const u32x4 ql = *reinterpret_cast<const u32x4 *>(slab + st * 8192 + (32 * jt + r) * 64 + off_l);
-                    acc2[jt] = ARC_MFMA(tl, qh, acc2[jt]);
-                    acc2[jt] = ARC_MFMA(th, ql, acc2[jt]);
-                    acc2[jt] = ARC_MFMA(th, qh, acc2[jt]);
-                }
+        for (int c = 0; c < NT; ++c) {
+            {  // slab c landed; the slabs issued behind it (up to DB - 1 of them) may stay in flight
+                const int behind = (NT - 1 - c) < (DB - 1) ? (NT - 1 - c) : (DB - 1);  // a constant once the loop is unrolled
+                if (behind >= 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else if (behind == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else if (behind == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the patch is rewritten for the next chunk
+            lds_barrier();  // ... and the chunk's patch is written
+            const unsigned char *slab = lds + (c % NSLAB) * SLAB_B;
+            const unsigned char *pt = patch + (c & 1) * 4096;
+            const unsigned ld = lds0 + (unsigned)(((c + DB) % NSLAB) * SLAB_B);
+            u32x4 th[2], tl[2];
+#pragma unroll
+            for (int st2 = 0; st2 < 2; ++st2) {
+                th[st2] = *reinterpret_cast<const u32x4 *>(pt + st2 * 2048 + r * 64 + off_h);
+                tl[st2] = *reinterpret_cast<const u32x4 *>(pt + st2 * 2048 + r * 64 + off_l);
+            }
+            // four groups (stage, column tile) of three MFMAs: the next group's fragments are read in front of a group, one
+            // of the two LDS-DMA issues of slab c + 2 follows every other group
+            u32x4 qh[2], ql[2];
+            auto read_q = [&](int gi, int slot) {
+                const int st2 = gi >> 1, jt = 2 * nh + (gi & 1);
+                qh[slot] = *reinterpret_cast<const u32x4 *>(slab + st2 * 8192 + (32 * jt + r) * 64 + off_h);
+                ql[slot] = *reinterpret_cast<const u32x4 *>(slab + st2 * 8192 + (32 * jt + r) * 64 + off_l);
+            };
+            read_q(0, 0);
+#pragma unroll
+            for (int gi = 0; gi < 4; ++gi) {  // both column tiles whatever L is: branch-free (columns >= L are masked)
+                const int st2 = gi >> 1, k = gi & 1, sl = gi & 1;
+                if (gi + 1 < 4) read_q(gi + 1, sl ^ 1);
+                acc2[k] = ARC_MFMA(tl[st2], qh[sl], acc2[k]);
+                acc2[k] = ARC_MFMA(th[st2], ql[sl], acc2[k]);
+                acc2[k] = ARC_MFMA(th[st2], qh[sl], acc2[k]);
+                ARC_PIN(acc2[k]);
+                if ((gi & 1) && c + DB < NT) arc_dma16(srcB[gi >> 1] + (long)(c + DB) * 128, ld + (gi >> 1) * 8192);
+            }
+            // the next chunk into the other patch, beside this chunk's MFMAs, by the half that holds it
+            if (c + 1 < NT && nh == (c + 1) / NTW) convert(c + 1, (c + 1) % NTW);
         }
+        ARC_STAMP(3 + 4 * s);
         // ------------------------------------------------------------------------------------------ the scorer's term
+        // The running sum of the scorers' terms lives in the output rows themselves (every lane re-reads what it wrote:
+        // 128-byte row segments, L2-resident); the softmax below reads the finished rows back.
         float fi[16];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) fi[e] = rowfac[acc_row(e, lane)];
+        for (int e = 0; e < 16; ++e) fi[e] = rowfac[mt * 32 + acc_row(e, lane)];
+        float prev[2][16];  // both column tiles' loads in flight together
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt) {
-            const int j = 32 * jt + r;
+        for (int k = 0; k < 2; ++k) {
+            const int j = 32 * (2 * nh + k) + r;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int i = 32 * wave + acc_row(e, lane);
-                const float x = acc2[jt][e] * fi[e] * gj[jt];
+                const int il = acc_row(e, lane);
+                prev[k][e] = (s > 0 && j < L && 32 * mt + il < L) ? obase[(long)il * L + j] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int j = 32 * (2 * nh + k) + r;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int il = acc_row(e, lane), i = 32 * mt + il;
+                const float x = acc2[k][e] * fi[e] * gj[k];
                 const int d = j - i;
-                float v = cell[jt][e];
+                float v = prev[k][e];
                 if (s == 0) {
                     v = x;
                 } else if (s == 1) {
@@ -265,42 +375,46 @@ __global__ __launch_bounds__(256, 1) void arc_f16x3_kernel(ArcSplitArgs a) {
                 } else if (a.use_dist) {
                     const float pred = 1.f + arcs_softplus(x);
                     const float dd = fabsf((float)d) - pred;
-                    v += -logf(dd * dd / 2.f + 1.f);
+                    v += -__logf(dd * dd / 2.f + 1.f);
                 }
-                cell[jt][e] = v;
+                if (j < L && i < L) obase[(long)il * L + j] = v;
             }
-            __builtin_amdgcn_sched_barrier(0);  // one column tile's transcendentals at a time (register pressure)
         }
+        ARC_STAMP(4 + 4 * s);
     }
     // ---------------------------------------------------------------------------------------------- log-softmax, store
+    // over ALL L head columns, padding included (:214), diagonal -inf (:210-211): a wavefront per row, sixteen rows each,
+    // on the sums the block's wavefronts left in the output rows
+    __syncthreads();
+#pragma unroll 1
+    for (int k0 = 0; k0 < 16; k0 += 8) {  // eight rows' loads in flight at a time
+        float v0[8], v1[8];
+        const int j0 = lane, j1 = lane + 64;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int i = 32 * wave + acc_row(e, lane);
-        float v[4], m = -INFINITY;
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt) {
-            const int j = 32 * jt + r;
-            v[jt] = (j < L) ? (j == i ? -INFINITY : cell[jt][e]) : -INFINITY;
-            m = fmaxf(m, v[jt]);
+        for (int k = 0; k < 8; ++k) {
+            const int i = 16 * wave + k0 + k;
+            const float *orow = a.out + ((long)b * L + (i < L ? i : 0)) * L;
+            v0[k] = (i < len && j0 < L && j0 != i) ? orow[j0] : -INFINITY;
+            v1[k] = (i < len && j1 < L && j1 != i) ? orow[j1] : -INFINITY;
         }
 #pragma unroll
-        for (int o = 1; o < 32; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
-        float sum = 0.f;
+        for (int k = 0; k < 8; ++k) {
+            const int i = 16 * wave + k0 + k;
+            float m = fmaxf(v0[k], v1[k]);
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt) sum += (32 * jt + r < L) ? expf(v[jt] - m) : 0.f;
+            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+            float sum = __expf(v0[k] - m) + __expf(v1[k] - m);
 #pragma unroll
-        for (int o = 1; o < 32; o <<= 1) sum += __shfl_xor(sum, o);
-        const float ls = logf(sum);
-        if (i < len) {
-            float *orow = a.out + ((long)b * L + i) * L;
-#pragma unroll
-            for (int jt = 0; jt < 4; ++jt) {
-                const int j = 32 * jt + r;
-                if (j < L) orow[j] = (v[jt] - m) - ls;
+            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+            const float ls = __logf(sum);
+            if (i < len) {  // wave-uniform (packed: padded dependents are not scored)
+                float *orow = a.out + ((long)b * L + i) * L;
+                if (j0 < L) orow[j0] = (v0[k] - m) - ls;
+                if (j1 < L) orow[j1] = (v1[k] - m) - ls;
             }
         }
-        __builtin_amdgcn_sched_barrier(0);  // one row at a time
     }
+    ARC_STAMP(13);
 }
 
 int arc_split_kc(int H) {  // columns per image segment: the smallest supported multiple of 32 that holds H + 1 features
@@ -322,7 +436,7 @@ static int launch_arc_split(const ArcSplitArgs &a, hipStream_t stream) {
         once.mark(dev);
     }
     ProfScope ps("arc_fused", stream);
-    hipLaunchKernelGGL(arc_f16x3_kernel<NT>, dim3(a.B), dim3(256), ArcSplitLayout<NT>::TOTAL, stream, a);
+    hipLaunchKernelGGL(arc_f16x3_kernel<NT>, dim3(a.B), dim3(512), ArcSplitLayout<NT>::TOTAL, stream, a);
     return check_launch("arc_f16x3_kernel");
 }
 
@@ -351,6 +465,9 @@ extern "C" int phonlp_arc_scores_split(const void *XFp, const float *x_inv, int 
     a.B = B; a.L = L; a.S = n_scorers; a.rows_total = rows_total;
     a.use_lin = use_lin; a.use_dist = use_dist;
     a.off = off; a.sentlens = sentlens; a.pad = (const unsigned char *)pad_row; a.pad_inv = pad_inv;
+#ifdef ARC_STAMPS
+    a.dbg = getenv("PHONLP_ARC_DBG") ? (long long *)strtoull(getenv("PHONLP_ARC_DBG"), nullptr, 0) : nullptr;
+#endif
     switch (KC) {
         case 64: return launch_arc_split<2>(a, as_stream(stream));
         case 128: return launch_arc_split<4>(a, as_stream(stream));

@@ -68,10 +68,11 @@ enum { CT_STARTED = 0, CT_FIRST_DONE = 1, CT_Q_TAIL = 2, CT_Q_HEAD = 3, CT_FB = 
 #define NEG_INF_D (-__builtin_inf())
 
 // The margin of the round-based decoders (mst_fast.hip's header has the argument): a selection is used only if its
-// maximum beats every other option by MORE than tau = 16 l^3 2^-53 max|entry|.  The reference's own float64 rounding
-// (and these kernels') moves the weight of the tree it returns by at most ~10 l^2 2^-53 max|entry|, a factor ~l below.
+// maximum beats every other option by MORE than tau = 64 l^2 2^-53 max|entry|.  The reference's own float64 rounding
+// moves the weight of the tree it returns by at most 12 l^2 2^-53 max|entry|, these kernels' own compared values are off
+// by at most 6 l^2 2^-53 max|entry| each: 24 l^2 in all for a comparison, a factor 2.7 below tau.
 __host__ __device__ inline double mst_margin(int l, float amax) {
-    return 16.0 * (double)l * (double)l * (double)l * 1.1102230246251565e-16 * (double)amax;
+    return 64.0 * (double)l * (double)l * 1.1102230246251565e-16 * (double)amax;
 }
 
 // numpy's float64 pairwise add-reduction order (verified against numpy 2.2, n = 1..1000).

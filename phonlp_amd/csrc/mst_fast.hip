@@ -6,7 +6,7 @@
 //
 //  (M) margin.  Every selection made here -- the best head of a row among the columns outside its component, the best
 //      member row of a contracted column that is chosen, the best column of a new component, the best single-root
-//      candidate -- beats every other option by MORE than tau = 16 l^3 2^-53 max|entry| (mst_margin(); entries: the
+//      candidate -- beats every other option by MORE than tau = 64 l^2 2^-53 max|entry| (mst_margin(); entries: the
 //      finite ones of rows >= 1 off the diagonal; NaN or +inf anywhere: fallback).
 //
 //  Why that suffices (u = 2^-53, A = max|entry|, every value anyone forms is a sum of at most l entries, so |value| <= lA):
@@ -18,14 +18,18 @@
 //     unchanged (the new column is a maximum over old columns) and the new node's in-edge and the member row behind a
 //     chosen column are checked here.  By induction over the rounds (disjoint cycles of a round commute): the tree T*
 //     decoded here is THE maximum arborescence, and every other arborescence weighs less by at least the smallest margin
-//     seen, i.e. by more than tau minus this kernel's own rounding (its compared values carry <= ~3 l^2 u A).
+//     seen, i.e. by more than tau minus this kernel's own rounding (see 2.).
 //  2. The reference returns a near-maximum arborescence.  It compares stored float64 values exactly (np.argmax); what
 //     rounds are the entries it forms per contraction, (s - e_m) + sum(e) (:73-84): at most (c + 4) u lA off per entry
 //     for a cycle of c members.  A tree of the contracted graph uses ONE such entry, so by induction over its recursion
 //     (exact Chu-Liu-Edmonds on the entries as stored, the optimum of a level equal to that of its exact contraction)
-//     the tree it returns is within sum over levels of 2 (c + 4) u lA <= 10 l^2 u A of the maximum -- a factor ~l
-//     below tau.  Hence it returns T*.  The same for each single-root candidate (:143-160), whose tree scores (l-term
-//     float64 sums, <= l^2 u A off) it compares with strict '>': the pick here requires the best candidate to lead by tau.
+//     the tree it returns is within sum over levels of 2 (c + 4) u lA <= 12 l^2 u A of the maximum (the cycle sizes
+//     add up to at most 2l, the levels to at most l).  The values compared HERE, W[i][j] + off[i], carry the roundings of
+//     off[i]'s history: every merge adds (2c + 2) u lA on top of the errors of the OTHER members' sums (a row's own
+//     selected value enters the cycle total and is subtracted again: it cancels), additive over disjoint components, so
+//     <= 6 l^2 u A per value.  12 + 2 * 6 = 24 l^2 u A in all, a factor 2.7 below tau.  Hence it returns T*.  The same for each single-root candidate (:143-160),
+//     whose tree scores (l-term float64 sums, <= l^2 u A off) it compares with strict '>': the pick here requires the
+//     best candidate to lead by tau.
 //
 //  No exactness is assumed: scores of any dynamic range qualify (a trained parser's near-certain arcs, log-probabilities
 //  from -1e-7 to -50 in one row, never fit a common grid).  A sentence that fails (M) anywhere -- exact ties above all:
