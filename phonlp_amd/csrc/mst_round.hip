@@ -65,12 +65,16 @@ __device__ __forceinline__ void argmax_dpp(float &bv, int &bj, int &dup, float t
 // Best column of up to four rows among the columns outside each row's component (and not column 0 when `skip0`), by one
 // wavefront: lanes over columns, the loads of CG 64-column chunks of the four rows issued before their first
 // comparison (a rolled loop over the groups keeps the kernel inside its 128 registers).  Columns past the row's end are
-// read at the clamped column L - 1 (always inside the matrix) and masked.  Lane 0 stores best_j / best_v; a row whose
-// maximum does not lead by more than tau, or an empty row, raises sc[RS_FAIL].
+// read at the clamped column L - 1 (always inside the matrix) and masked.  Lane 0 stores best_j / best_v and the row's
+// flag rowdup[i] = "its maximum does not lead by more than tau".  The flag fails the decode only if the row's edge is
+// SELECTED (the row of a singleton component after the first scan; later the winning row of a merged component): the
+// argument in mst_fast.hip's header needs the margin of a component's best in-edge against its other in-edges -- for
+// the other rows of the component that is the margin of their best values against the winner's, checked where the
+// winner is picked; their own runner-up columns never enter.  Most rescanned rows are not winners.
 // (`dup` is an int on purpose: as a bool the four-row unrolled form sends the compiler into a minutes-long search.)
 template <int NCH, int CG>
 __device__ __forceinline__ void scan_rows4(const float *arc, int L, int l, const int *comp, const int (&rows)[4], int nrows,
-                                           bool skip0, int root, int lane, int *bestJ, float *bestV, int *sc, float tau) {
+                                           bool skip0, int root, int lane, int *bestJ, float *bestV, int *rowdup, float tau) {
     const float NEGF = -__builtin_inff();
     float bv[4];
     int bj[4], ci[4], ri[4], dup[4];
@@ -125,7 +129,7 @@ __device__ __forceinline__ void scan_rows4(const float *arc, int L, int l, const
             if (i == root) { bv[r] = 0.f; bj[r] = 0; d = 0; }  // set_root: the row's only edge, weight 0 (:147-148)
             bestJ[i] = bj[r];
             bestV[i] = bv[r];
-            if (d || !(bv[r] > NEGF)) sc[RS_FAIL] = 1;
+            rowdup[i] = (d || !(bv[r] > NEGF)) ? 1 : 0;
         }
     }
 }
@@ -171,8 +175,8 @@ __global__ __launch_bounds__(1024) void mst_round_kernel(MstArgs a) {
     int *comp = reinterpret_cast<int *>(dsum + 2);
     int *bestJ = comp + L, *selI = bestJ + L, *selJ = selI + L, *wA = selJ + L, *wB = wA + L, *lab = wB + L;
     int *mark = lab + L, *cnt = mark + L, *list = cnt + L, *rI1 = list + L, *rJ1 = rI1 + L, *cS1 = rJ1 + L;
-    int *sp0 = cS1 + L, *sp1 = sp0 + L, *sp2 = sp1 + L;  // spare (kRoundInts = 16)
-    (void)sp0; (void)sp1; (void)sp2;
+    int *rowdup = cS1 + L, *sp1 = rowdup + L, *sp2 = sp1 + L;  // (two spare: kRoundInts = 16)
+    (void)sp1; (void)sp2;
     float *bestV = reinterpret_cast<float *>(sp2 + L);
     int *sc = reinterpret_cast<int *>(bestV + L);
     int *wcnt = sc + RS_COUNT;  // 16 entries
@@ -230,14 +234,16 @@ __global__ __launch_bounds__(1024) void mst_round_kernel(MstArgs a) {
         const bool skip0 = root >= 1;
         __syncthreads();
         if (tid == 0) sc[RS_FAIL] = 0;
-        if (node) { comp[v] = v; off[v] = 0.0; selI[v] = v; mark[v] = 0; bestJ[v] = 0; bestV[v] = 0.f; }
+        if (node) { comp[v] = v; off[v] = 0.0; selI[v] = v; mark[v] = 0; bestJ[v] = 0; bestV[v] = 0.f; rowdup[v] = 0; }
         __syncthreads();
         // ---- first arg-max of every row (ref :58)
         for (int r0 = 1 + 4 * wave; r0 < l; r0 += 4 * nw) {
             const int rows[4] = {r0, r0 + 1, r0 + 2, r0 + 3};
             const int n = l - r0 < 4 ? l - r0 : 4;
-            scan_rows4<NCH, CG>(arc, L, l, comp, rows, n, skip0, root, lane, bestJ, bestV, sc, tauf);
+            scan_rows4<NCH, CG>(arc, L, l, comp, rows, n, skip0, root, lane, bestJ, bestV, rowdup, tauf);
         }
+        __syncthreads();
+        if (node && v >= 1 && rowdup[v]) sc[RS_FAIL] = 1;  // every row is its own component here: its edge is selected
         __syncthreads();
         if (node && v >= 1) { selJ[v] = bestJ[v]; selV[v] = (double)bestV[v]; }
         STAMP(0);
@@ -306,7 +312,7 @@ __global__ __launch_bounds__(1024) void mst_round_kernel(MstArgs a) {
                     const int m = n - k0 < 4 ? n - k0 : 4;
                     const int rows[4] = {list[k0], list[k0 + (m > 1 ? 1 : 0)], list[k0 + (m > 2 ? 2 : 0)],
                                          list[k0 + (m > 3 ? 3 : 0)]};
-                    scan_rows4<NCH, CG>(arc, L, l, comp, rows, m, skip0, root, lane, bestJ, bestV, sc, tauf);
+                    scan_rows4<NCH, CG>(arc, L, l, comp, rows, m, skip0, root, lane, bestJ, bestV, rowdup, tauf);
                 }
             }
             __syncthreads();
@@ -322,7 +328,7 @@ __global__ __launch_bounds__(1024) void mst_round_kernel(MstArgs a) {
             }
             __syncthreads();
             if (merged && key == ckey[nc]) {
-                if (atomicAdd(&cnt[nc], 1) > 0) sc[RS_FAIL] = 1;  // two rows attain it
+                if (atomicAdd(&cnt[nc], 1) > 0 || rowdup[v]) sc[RS_FAIL] = 1;  // two rows attain it / the winner's own runner-up
                 selI[nc] = v;
                 selJ[nc] = bestJ[v];
                 selV[nc] = val;
