@@ -187,7 +187,7 @@ int phonlp_biaffine_arc_scores(const float *XF, int B, int L, int H, int n_score
                                void *stream);
 
 /* Engine 2, stages A and B of the arc scorers in ONE kernel (biaffine.py:21-37 per scorer, annotate_model.py:192-214),
- * for sentences of up to 128 words and H + 1 <= 416: XFp / x_inv = the first-layer image phonlp_linear_split_image
+ * for sentences of up to 512 words and H + 1 <= 416: XFp / x_inv = the first-layer image phonlp_linear_split_image
  * wrote with N = n_scorers * 2 * KC columns, KC = phonlp_arc_kc(H) (per scorer the segments relu(W1 x + b1) | 1 | 0..
  * and relu(W2 x + b2) | 1 | 0.., KC columns each); Wbp / wb_inv = the split image of the packed bilinear weights with
  * every scorer's rows AND columns zero-padded to KC ([n_scorers * KC, KC]).  rows_total = rows of the image.  Packed

@@ -1,7 +1,8 @@
 // Arc scorers on engine 2, stages A and B of the three one-output scorers fused (ref: models/common/biaffine.py:21-37 per
 // scorer, annotate_model.py:189-214 for the terms and the log-softmax).
 //
-// One workgroup = one sentence (L <= 128 words), four wavefronts, wavefront w = dependents 32w .. 32w+31.  Per scorer:
+// One workgroup = 128 dependents of one sentence (L <= 512 words) against all its heads, eight wavefronts = (row tile of 32
+// dependents) x (half: of the output features in phase A, of a group's head columns in phase B).  Per scorer:
 //
 //   phase A  Ta^T[n][i] = sum_k Wb[n][k] X1[i][k]      (bilinear stage A, :27-29, taken TRANSPOSED: rows = the KC output
 //            features n, columns = the wave's 32 dependents).  Operands are split images (f16 pieces h, l; three
@@ -104,7 +105,9 @@ struct ArcSplitLayout {
     static constexpr int TOTAL = RING + (4 * 32 + 2 * 4 * 32 + NA * 32) * 4;  // + row factors, row maxima, weight-row scales
 };
 
-template <int NT>
+// LONG = false: sentences of up to 128 words (one block per sentence, one group of head columns: the loops over them fold
+// away, which the register allocation of the headline shape needs); true: up to 512.
+template <int NT, bool LONG>
 __global__ __launch_bounds__(512, 1) void arc_f16x3_kernel(ArcSplitArgs a) {
     using Ly = ArcSplitLayout<NT>;
     constexpr int KC = Ly::KC, NTW = Ly::NTW, NLW = Ly::NLW, STAGE_A = Ly::STAGE_A, SLAB_B = Ly::SLAB_B;
@@ -113,7 +116,10 @@ __global__ __launch_bounds__(512, 1) void arc_f16x3_kernel(ArcSplitArgs a) {
     const int mt = wave & 3, nh = wave >> 2;  // row tile (dependents 32 mt ..), half (phase A: output features; B: head columns)
     const int r = lane & 31, hh = lane >> 5;
     const int b = blockIdx.x, L = a.L;
+    const int i0 = LONG ? 128 * blockIdx.y : 0;  // the block's dependents: i0 .. i0 + 127 (sentences longer than 128 words: several blocks)
     const int len = a.off ? min(max(a.sentlens[b], 0), L) : L;  // dependents scored; heads j < len are real rows
+    if (i0 >= len) return;  // packed: nothing but padded dependents here (block-uniform)
+    const int NJG = LONG ? (L + 127) >> 7 : 1;   // groups of 128 head columns
     const long rowbase = a.off ? a.off[b] : (long)b * L;
     float *rowfac = reinterpret_cast<float *>(lds + Ly::RING);  // [4][32]
     float *rmax = rowfac + 4 * 32;                              // [2][4][32]
@@ -133,16 +139,8 @@ __global__ __launch_bounds__(512, 1) void arc_f16x3_kernel(ArcSplitArgs a) {
         return a.XF + row * a.pitch_x;
     };
 
-    float gj[2];  // inverse scale of the heads' image rows (the X2 side) of the wave's two column tiles
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int j = 32 * (2 * nh + k) + r;
-        long row = rowbase + j;
-        row = row < a.rows_total ? row : a.rows_total - 1;
-        gj[k] = (a.off && j >= len) ? a.pad_inv : a.x_inv[row];
-    }
-    const float xi = a.x_inv[min(rowbase + 32 * mt + r, (long)a.rows_total - 1)];  // the lane's dependent
-    float *obase = a.out + ((long)b * L + 32 * mt) * L;
+    const float xi = a.x_inv[min(rowbase + i0 + 32 * mt + r, (long)a.rows_total - 1)];  // the lane's dependent
+    float *obase = a.out + ((long)b * L + i0 + 32 * mt) * L;
 
     ARC_STAMP(0);
 #pragma unroll 1
@@ -153,7 +151,7 @@ __global__ __launch_bounds__(512, 1) void arc_f16x3_kernel(ArcSplitArgs a) {
         for (int q = 0; q < NLW; ++q) {
             const int u = 8 * q + wave;
             if (u < 8) {
-                srcA[q] = xrow(16 * u + lr) + (long)(2 * s) * KC * 4 + chunk * 16;
+                srcA[q] = xrow(i0 + 16 * u + lr) + (long)(2 * s) * KC * 4 + chunk * 16;
             } else {
                 int n = 16 * (u - 8) + lr;
                 n = n < KC ? n : KC - 1;  // the pad tile's rows and dummy wave-loads: any valid row
@@ -233,32 +231,25 @@ __global__ __launch_bounds__(512, 1) void arc_f16x3_kernel(ArcSplitArgs a) {
         }
         ARC_STAMP(1 + 4 * s);
         // ------------------------------------------------------------------------------------------ phase B
-        // the heads' X2 slabs: chunk c = two k16 stages of 128 rows, two wave-loads per wavefront
-        const unsigned char *srcB[2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int u = 8 * q + wave;         // 0..15: stage u >> 3, rows 16 (u & 7) ..
-            const int j = 16 * (u & 7) + lr;
-            const unsigned char *rowp = (a.off && j >= len && j < L) ? a.pad : xrow(j);
-            srcB[q] = rowp + (long)(2 * s + 1) * KC * 4 + (u >> 3) * 64 + chunk * 16;
-        }
-        auto issueB = [&](int c, int buf) {
-#pragma unroll
-            for (int q = 0; q < 2; ++q) arc_dma16(srcB[q] + (long)c * 128, lds0 + (unsigned)(buf * SLAB_B + q * 8192));
-        };
         constexpr int NSLAB = Ly::NSLAB, DB = NSLAB - 1;  // DB slabs ahead
-#pragma unroll
-        for (int c = 0; c < DB && c < NT; ++c) issueB(c, c);
-        // Ta' = acc * wb_inv[n] (exact: powers of two); the row's maximum over BOTH halves -> its power-of-two scale
+        // Ta' = acc * wb_inv[n] (exact: powers of two), once, in place; the row's maximum over BOTH halves -> its
+        // power-of-two scale.  (The weight rows' scales come from LDS through a base the compiler cannot see through:
+        // it hoists the fifty lane-dependent LDS addresses of an unrolled form out of the scorer loop, spills them, and
+        // every reload waits for vmcnt(0), i.e. for the LDS-DMA transfers in flight.)
         float amax = 0.f;
+        {
+            const float *wsc = wscale + 4 * hh;
+            asm volatile("" : "+v"(wsc));
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) {
-            if (nh * NTW + t < NT) {  // wave-uniform: not the pad tile
+            for (int t = 0; t < NTW; ++t) {
+                if (nh * NTW + t < NT) {  // wave-uniform: not the pad tile
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float4 wi = *reinterpret_cast<const float4 *>(wscale + 32 * (nh * NTW + t) + 8 * g + 4 * hh);
-                    amax = fmaxf(amax, fmaxf(fmaxf(fabsf(acc[t][4 * g + 0] * wi.x), fabsf(acc[t][4 * g + 1] * wi.y)),
-                                             fmaxf(fabsf(acc[t][4 * g + 2] * wi.z), fabsf(acc[t][4 * g + 3] * wi.w))));
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 wi = *reinterpret_cast<const float4 *>(wsc + 32 * (nh * NTW + t) + 8 * g);
+                        acc[t][4 * g + 0] *= wi.x; acc[t][4 * g + 1] *= wi.y; acc[t][4 * g + 2] *= wi.z; acc[t][4 * g + 3] *= wi.w;
+                        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(acc[t][4 * g + 0]), fabsf(acc[t][4 * g + 1])),
+                                                 fmaxf(fabsf(acc[t][4 * g + 2]), fabsf(acc[t][4 * g + 3]))));
+                    }
                 }
             }
         }
@@ -271,23 +262,17 @@ __global__ __launch_bounds__(512, 1) void arc_f16x3_kernel(ArcSplitArgs a) {
         const float tscale = __uint_as_float((unsigned)(268 - E) << 23);  // maximum -> [2^14, 2^15)
         const float tinv = __uint_as_float((unsigned)(E - 14) << 23);
         if (nh == 0 && hh == 0) rowfac[mt * 32 + r] = tinv * xi;
-        f32x16 acc2[2];
-#pragma unroll
-        for (int k = 0; k < 2; ++k)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc2[k][e] = 0.f;
         // a chunk's pieces into one of the row tile's two patches: row r, stage g >> 1, eight bytes of chunk 2 (g & 1) (+1: low
         // piece); written by the wavefront that holds the chunk (tile t of its half)
         auto convert = [&](int c, int t) {
+            (void)c;
             unsigned char *pt = patch + (c & 1) * 4096;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 af16x4 h4, l4;
-                const float4 wi4 = *reinterpret_cast<const float4 *>(wscale + 32 * c + 8 * g + 4 * hh);
-                const float wi[4] = {wi4.x * tscale, wi4.y * tscale, wi4.z * tscale, wi4.w * tscale};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float v = acc[t][4 * g + e] * wi[e];
+                    const float v = acc[t][4 * g + e] * tscale;
                     h4[e] = (_Float16)v;
                     l4[e] = (_Float16)(v - (float)h4[e]);
                 }
@@ -296,8 +281,41 @@ __global__ __launch_bounds__(512, 1) void arc_f16x3_kernel(ArcSplitArgs a) {
                 *reinterpret_cast<af16x4 *>(p + (((2 * (g & 1) + 1) ^ sw) << 4)) = l4;
             }
         };
-        if (nh == 0) convert(0, 0);
         ARC_STAMP(2 + 4 * s);
+        float fi[16];
+#pragma unroll 1
+        for (int jg = 0; jg < NJG; ++jg) {  // 128 head columns at a time (one trip for sentences of up to 128 words)
+        const int jbase = 128 * jg;
+        // the heads' X2 slabs: chunk c = two k16 stages of 128 rows, two wave-loads per wavefront
+        const unsigned char *srcB[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int u = 8 * q + wave;         // 0..15: stage u >> 3, rows 16 (u & 7) ..
+            const int j = jbase + 16 * (u & 7) + lr;
+            const unsigned char *rowp = (a.off && j >= len && j < L) ? a.pad : xrow(j);
+            srcB[q] = rowp + (long)(2 * s + 1) * KC * 4 + (u >> 3) * 64 + chunk * 16;
+        }
+        auto issueB = [&](int c, int buf) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) arc_dma16(srcB[q] + (long)c * 128, lds0 + (unsigned)(buf * SLAB_B + q * 8192));
+        };
+        float gj[2];  // inverse scale of the heads' image rows (the X2 side) of the wave's two column tiles
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int j = jbase + 32 * (2 * nh + k) + r;
+            long row = rowbase + j;
+            row = row < a.rows_total ? row : a.rows_total - 1;
+            gj[k] = (a.off && j >= len) ? a.pad_inv : a.x_inv[row];
+        }
+        if (jg > 0) lds_barrier();  // the previous group's slabs and patches have been read
+#pragma unroll
+        for (int c = 0; c < DB && c < NT; ++c) issueB(c, c);
+        f32x16 acc2[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc2[k][e] = 0.f;
+        if (nh == 0) convert(0, 0);
 #pragma unroll
         for (int c = 0; c < NT; ++c) {
             {  // slab c landed; the slabs issued behind it (up to DB - 1 of them) may stay in flight
@@ -330,87 +348,169 @@ __global__ __launch_bounds__(512, 1) void arc_f16x3_kernel(ArcSplitArgs a) {
             for (int gi = 0; gi < 4; ++gi) {  // both column tiles whatever L is: branch-free (columns >= L are masked)
                 const int st2 = gi >> 1, k = gi & 1, sl = gi & 1;
                 if (gi + 1 < 4) read_q(gi + 1, sl ^ 1);
+#if !defined(ARC_ABL) || ARC_ABL != 2
                 acc2[k] = ARC_MFMA(tl[st2], qh[sl], acc2[k]);
                 acc2[k] = ARC_MFMA(th[st2], ql[sl], acc2[k]);
                 acc2[k] = ARC_MFMA(th[st2], qh[sl], acc2[k]);
+#else
+                acc2[k][0] += __uint_as_float(tl[st2][0] ^ qh[sl][0] ^ th[st2][1] ^ ql[sl][1]);
+#endif
                 ARC_PIN(acc2[k]);
                 if ((gi & 1) && c + DB < NT) arc_dma16(srcB[gi >> 1] + (long)(c + DB) * 128, ld + (gi >> 1) * 8192);
             }
             // the next chunk into the other patch, beside this chunk's MFMAs, by the half that holds it
+#if !defined(ARC_ABL) || ARC_ABL != 1
             if (c + 1 < NT && nh == (c + 1) / NTW) convert(c + 1, (c + 1) % NTW);
+#endif
         }
         ARC_STAMP(3 + 4 * s);
         // ------------------------------------------------------------------------------------------ the scorer's term
         // The running sum of the scorers' terms lives in the output rows themselves (every lane re-reads what it wrote:
         // 128-byte row segments, L2-resident); the softmax below reads the finished rows back.
-        float fi[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) fi[e] = rowfac[mt * 32 + acc_row(e, lane)];
-        float prev[2][16];  // both column tiles' loads in flight together
+        float *ob = obase + (lane >> 5) * 4 * (long)L + jbase + 64 * nh + r;  // row 4 (lane >> 5), the wave's first column tile
+        int dj = jbase + 64 * nh + r - (i0 + 32 * mt + 4 * hh);                   // j - i of that cell
+        asm volatile("" : "+v"(ob), "+v"(dj));  // (everything derived from them is derived HERE: hoisted out of the scorer loop,
+                                                // the 32 cells' addresses and offsets were spilled and reloaded one by one)
+        // cell (k, e): row 4 hh + (e & 3) + 8 (e >> 2) of the row tile, column 32 k of the wave's pair; one loop per scorer, the
+        // scorer switch outside it
+        auto cell_ok = [&](int k, int e) {
+            return jbase + 32 * (2 * nh + k) + r < L && i0 + 32 * mt + acc_row(e, lane) < L;
+        };
+        if (s == 0) {
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int j = 32 * (2 * nh + k) + r;
+            for (int k = 0; k < 2; ++k)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int il = acc_row(e, lane);
-                prev[k][e] = (s > 0 && j < L && 32 * mt + il < L) ? obase[(long)il * L + j] : 0.f;
-            }
-        }
+                for (int e = 0; e < 16; ++e)
+                    if (cell_ok(k, e)) ob[(long)((e & 3) + 8 * (e >> 2)) * L + 32 * k] = acc2[k][e] * fi[e] * gj[k];
+        } else if ((s == 1 && a.use_lin) || (s == 2 && a.use_dist)) {
+            float prev[2][16];  // both column tiles' loads in flight together
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int j = 32 * (2 * nh + k) + r;
+            for (int k = 0; k < 2; ++k)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int il = acc_row(e, lane), i = 32 * mt + il;
-                const float x = acc2[k][e] * fi[e] * gj[k];
-                const int d = j - i;
-                float v = prev[k][e];
-                if (s == 0) {
-                    v = x;
-                } else if (s == 1) {
-                    if (a.use_lin) {
+                for (int e = 0; e < 16; ++e) prev[k][e] = cell_ok(k, e) ? ob[(long)((e & 3) + 8 * (e >> 2)) * L + 32 * k] : 0.f;
+            if (s == 1) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int d = dj + 32 * k - ((e & 3) + 8 * (e >> 2));
+                        const float x = acc2[k][e] * fi[e] * gj[k];
                         const float sg = d > 0 ? 1.f : (d < 0 ? -1.f : 0.f);
-                        v += arcs_log_sigmoid(x * sg);
+                        prev[k][e] += arcs_log_sigmoid(x * sg);
                     }
-                } else if (a.use_dist) {
-                    const float pred = 1.f + arcs_softplus(x);
-                    const float dd = fabsf((float)d) - pred;
-                    v += -__logf(dd * dd / 2.f + 1.f);
-                }
-                if (j < L && i < L) obase[(long)il * L + j] = v;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int d = dj + 32 * k - ((e & 3) + 8 * (e >> 2));
+                        const float x = acc2[k][e] * fi[e] * gj[k];
+                        const float dd = fabsf((float)d) - (1.f + arcs_softplus(x));
+                        prev[k][e] += -__logf(dd * dd / 2.f + 1.f);
+                    }
             }
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if (cell_ok(k, e)) ob[(long)((e & 3) + 8 * (e >> 2)) * L + 32 * k] = prev[k][e];
         }
+        }  // column groups
         ARC_STAMP(4 + 4 * s);
     }
     // ---------------------------------------------------------------------------------------------- log-softmax, store
     // over ALL L head columns, padding included (:214), diagonal -inf (:210-211): a wavefront per row, sixteen rows each,
     // on the sums the block's wavefronts left in the output rows
     __syncthreads();
-#pragma unroll 1
-    for (int k0 = 0; k0 < 16; k0 += 8) {  // eight rows' loads in flight at a time
-        float v0[8], v1[8];
-        const int j0 = lane, j1 = lane + 64;
+    if constexpr (!LONG) {
+        // sixteen rows per wavefront, FOUR LANES PER ROW (lane = 4 row + quarter): a lane reduces its 32 columns in its own
+        // registers and two exchanges finish the row (a lane per column pair took twelve dependent cross-lane steps per row)
+        const int i = 16 * wave + (lane >> 2), q4 = lane & 3;
+        float *orow = a.out + ((long)b * L + (i < L ? i : 0)) * L + 32 * q4;
+        const bool vec = (L & 3) == 0;  // 16-byte aligned rows
+        float v[32];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int i = 16 * wave + k0 + k;
-            const float *orow = a.out + ((long)b * L + (i < L ? i : 0)) * L;
-            v0[k] = (i < len && j0 < L && j0 != i) ? orow[j0] : -INFINITY;
-            v1[k] = (i < len && j1 < L && j1 != i) ? orow[j1] : -INFINITY;
+        for (int c = 0; c < 8; ++c) {
+            float4 t = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+            const int j = 32 * q4 + 4 * c;
+            if (i < len) {
+                if (vec && j + 3 < L) t = *reinterpret_cast<const float4 *>(orow + 4 * c);
+                else {
+                    if (j < L) t.x = orow[4 * c];
+                    if (j + 1 < L) t.y = orow[4 * c + 1];
+                    if (j + 2 < L) t.z = orow[4 * c + 2];
+                    if (j + 3 < L) t.w = orow[4 * c + 3];
+                }
+            }
+            v[4 * c] = j == i ? -INFINITY : t.x;
+            v[4 * c + 1] = j + 1 == i ? -INFINITY : t.y;
+            v[4 * c + 2] = j + 2 == i ? -INFINITY : t.z;
+            v[4 * c + 3] = j + 3 == i ? -INFINITY : t.w;
         }
+        float m = -INFINITY;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int i = 16 * wave + k0 + k;
-            float m = fmaxf(v0[k], v1[k]);
+        for (int c = 0; c < 32; ++c) m = fmaxf(m, v[c]);
+        m = fmaxf(m, __shfl_xor(m, 1));
+        m = fmaxf(m, __shfl_xor(m, 2));
+        float sum = 0.f;
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-            float sum = __expf(v0[k] - m) + __expf(v1[k] - m);
+        for (int c = 0; c < 32; ++c) sum += __expf(v[c] - m);  // (exp(-inf - m) = 0: masked columns, the diagonal)
+        sum += __shfl_xor(sum, 1);
+        sum += __shfl_xor(sum, 2);
+        const float ls = __logf(sum);
+        if (i < len) {
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-            const float ls = __logf(sum);
-            if (i < len) {  // wave-uniform (packed: padded dependents are not scored)
-                float *orow = a.out + ((long)b * L + i) * L;
-                if (j0 < L) orow[j0] = (v0[k] - m) - ls;
-                if (j1 < L) orow[j1] = (v1[k] - m) - ls;
+            for (int c = 0; c < 8; ++c) {
+                const int j = 32 * q4 + 4 * c;
+                const float4 t = make_float4((v[4 * c] - m) - ls, (v[4 * c + 1] - m) - ls, (v[4 * c + 2] - m) - ls,
+                                             (v[4 * c + 3] - m) - ls);
+                if (vec && j + 3 < L) *reinterpret_cast<float4 *>(orow + 4 * c) = t;
+                else {
+                    if (j < L) orow[4 * c] = t.x;
+                    if (j + 1 < L) orow[4 * c + 1] = t.y;
+                    if (j + 2 < L) orow[4 * c + 2] = t.z;
+                    if (j + 3 < L) orow[4 * c + 3] = t.w;
+                }
+            }
+        }
+    } else {  // up to 512 columns: eight values per lane, two rows' loads in flight
+#pragma unroll 1
+        for (int k0 = 0; k0 < 16; k0 += 2) {
+            float v[2][8];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int i = i0 + 16 * wave + k0 + k;
+                const float *orow = a.out + ((long)b * L + (i < L ? i : 0)) * L;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int j = lane + 64 * q;
+                    v[k][q] = (i < len && j < L && j != i) ? orow[j] : -INFINITY;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int i = i0 + 16 * wave + k0 + k;
+                float m = -INFINITY;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) m = fmaxf(m, v[k][q]);
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+                float sum = 0.f;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) sum += __expf(v[k][q] - m);
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+                const float ls = __logf(sum);
+                if (i < len) {
+                    float *orow = a.out + ((long)b * L + i) * L;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int j = lane + 64 * q;
+                        if (j < L) orow[j] = (v[k][q] - m) - ls;
+                    }
+                }
             }
         }
     }
@@ -430,13 +530,16 @@ static int launch_arc_split(const ArcSplitArgs &a, hipStream_t stream) {
     static PerDeviceOnce once;
     int dev;
     if (once.pending(&dev)) {
-        if (hipFuncSetAttribute((const void *)arc_f16x3_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void *)arc_f16x3_kernel<NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                ArcSplitLayout<NT>::TOTAL) != hipSuccess ||
+            hipFuncSetAttribute((const void *)arc_f16x3_kernel<NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 ArcSplitLayout<NT>::TOTAL) != hipSuccess)
             return fail(PHONLP_ERR_LAUNCH, "arc_scores_split: cannot raise the dynamic LDS limit");
         once.mark(dev);
     }
     ProfScope ps("arc_fused", stream);
-    hipLaunchKernelGGL(arc_f16x3_kernel<NT>, dim3(a.B), dim3(512), ArcSplitLayout<NT>::TOTAL, stream, a);
+    if (a.L <= 128) hipLaunchKernelGGL((arc_f16x3_kernel<NT, false>), dim3(a.B), dim3(512), ArcSplitLayout<NT>::TOTAL, stream, a);
+    else hipLaunchKernelGGL((arc_f16x3_kernel<NT, true>), dim3(a.B, (a.L + 127) / 128), dim3(512), ArcSplitLayout<NT>::TOTAL, stream, a);
     return check_launch("arc_f16x3_kernel");
 }
 
@@ -454,7 +557,7 @@ extern "C" int phonlp_arc_scores_split(const void *XFp, const float *x_inv, int 
     if (!XFp || !x_inv || !Wbp || !wb_inv || !arc_logp || B <= 0 || L <= 0 || rows_total <= 0 ||
         (n_scorers != 1 && n_scorers != 3))
         return fail(PHONLP_ERR_SHAPE, "arc_scores_split: bad argument");
-    if (KC == 0 || L > 128) return fail(PHONLP_ERR_UNSUPPORTED, "arc_scores_split: needs H + 1 <= 416 and L <= 128");
+    if (KC == 0 || L > 512) return fail(PHONLP_ERR_UNSUPPORTED, "arc_scores_split: needs H + 1 <= 416 and L <= 512");
     if (((uintptr_t)XFp & 15) || ((uintptr_t)Wbp & 15)) return fail(PHONLP_ERR_SHAPE, "arc_scores_split: images must be 16-byte aligned");
     if ((off != nullptr) != (sentlens != nullptr) || (off && !pad_row))
         return fail(PHONLP_ERR_SHAPE, "arc_scores_split: packed rows need off, sentlens and the pad row");

@@ -243,7 +243,7 @@ class TaskHeads:
             # joined fused form: 1 = the MST continues the main stream's queue behind the arc scores and the label
             # scorer's first layers go to a side stream (0: the MST on a side stream, the label layers on main)
             "mst_on_main": env("PHONLP_MST_ON_MAIN", "1") == "1",
-            # engine 2, sentences of up to 128 words: the arc scorers' stages A and B in one kernel, fed by the image the
+            # engine 2, sentences of up to 512 words: the arc scorers' stages A and B in one kernel, fed by the image the
             # W1/W2 layer writes (0: stage A as a GEMM of its own, stage B converting fp32 operands: the round-2 form)
             "arc_fused": env("PHONLP_ARC_FUSED", "1") == "1",
         }
@@ -606,7 +606,7 @@ class TaskHeads:
                 emb, arcW, labW = w.emb_eye, w.arc_W12p_s, w.lab_W12p_s
                 D = enc_dep.shape[2] + emb.shape[1]
             # the arc scorers' two bilinear stages as ONE kernel on the image their first layer writes (csrc/arc_f16x3.hip)
-            arc_fused = (cfg["arc_fused"] and w.arc_W12q_s is not None and Ld <= 128 and cfg["pos_fold"]
+            arc_fused = (cfg["arc_fused"] and w.arc_W12q_s is not None and Ld <= 512 and cfg["pos_fold"]
                          and w.arc_W12p_s is not None)
             if pack:
                 # Live words only from here to the labels (the reference's dense layers run on PackedSequence data,

@@ -21,7 +21,7 @@ def _finite_close(a, b, rtol, atol):
 @pytest.mark.parametrize("E,TE,H,U,O_,T", [(768, 100, 400, 24, 33, 9), (64, 12, 48, 7, 6, 5), (96, 20, 100, 9, 5, 4),
                                            (128, 16, 200, 11, 4, 6)])
 @pytest.mark.parametrize("B,L,ragged", [(16, 128, False), (9, 128, True), (7, 100, True), (5, 40, False), (3, 17, True),
-                                        (2, 2, False)])
+                                        (2, 2, False), (4, 200, True), (3, 300, False), (2, 512, True), (3, 129, False)])
 def test_fused_arc_vs_oracle_and_unfused(E, TE, H, U, O_, T, B, L, ragged):
     from phonlp_amd import HeadWeights, TaskHeads, ops
     from phonlp_amd import synthetic as S
