@@ -287,7 +287,8 @@ int phonlp_crf_nll_grad(const float *logits, const float *trans, const uint8_t *
  * harnesses that forbid hipMalloc).  No counterpart in the reference.  The B x T x T scratch of phonlp_crf_nll_grad
  * lives in a file-scope device array of phonlp_crf_nll_grad_static_max_bytes() = 4 MiB per GPU (held until the
  * process ends); B*T*T*4 bytes beyond that is rejected with PHONLP_ERR_UNSUPPORTED.  The call allocates and frees
- * nothing; the first call on a device looks the array's address up (hipGetSymbolAddress).  Every call on a GPU shares
+ * nothing; the first call on a device looks the array's address up (hipGetSymbolAddress, which may load the module's
+ * device variables): make that one call OUTSIDE graph capture, every later one may be captured.  Every call on a GPU shares
  * that GPU's array: calls that overlap on one GPU (two streams, two threads) race -- serialise them.  Nothing in the
  * array needs clearing between calls (every entry read was written by the same call).  Same results as
  * phonlp_crf_nll_grad, bit for bit. */

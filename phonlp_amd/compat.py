@@ -151,7 +151,25 @@ class DeepBiaffineScorer(nn.Module):
 
 # ---------------------------------------------------------------------------------------------------
 def _head_state(model):
-    return {k: v for k, v in model.state_dict().items() if not k.startswith("phobert.")}
+    """The head parameters and buffers under their state_dict names WITHOUT building the encoder's part of the
+    state_dict (that detaches ~200 PhoBERT tensors per call, on a path whose GPU step takes ~2 ms): the model's own
+    parameters and its children other than `phobert`, walked directly.  A model that keeps its heads elsewhere and
+    overrides state_dict() (tests/stub_model.py) is asked for its state_dict as before."""
+    sd = {}
+    for name, p in model.named_parameters(recurse=False):
+        sd[name] = p.detach()
+    for name, b in model.named_buffers(recurse=False):
+        sd[name] = b
+    for cname, child in model.named_children():
+        if cname == "phobert":
+            continue
+        for k, v in child.named_parameters(prefix=cname):
+            sd[k] = v.detach()
+        for k, v in child.named_buffers(prefix=cname):
+            sd[k] = v
+    if "dep_hid.weight" not in sd:
+        sd = {k: v for k, v in model.state_dict().items() if not k.startswith("phobert.")}
+    return sd
 
 
 def _fingerprint(sd):

@@ -635,10 +635,9 @@ static int arc_from_features(const float *XF, float *T, int B, int L, int KP, in
         attr_once.mark(attr_dev);
     }
     ProfScope ps("arc_stage_b", st);
-    static const bool rows32 = getenv("PHONLP_ARC_ROWS32") != nullptr;  // A/B switch
-    // 64 dependents per block (two blocks per CU) or 128 (one): PHONLP_ARC_ROWS, default 64
-    static const int rows = getenv("PHONLP_ARC_ROWS") ? atoi(getenv("PHONLP_ARC_ROWS")) : 64;
-    if (L <= 192 && !rows32) {
+    // 64 dependents per block (two blocks per CU: measured ahead of 128 per block) up to 192 words, 32 beyond
+    constexpr int rows = 64;
+    if (L <= 192) {
         if (rows == 64) {
             const size_t lds64 = (size_t)(192 * PITCH + 4 * 32 * 33 + 64 * a.LP) * sizeof(float);
             if (gemm_engine()) hipLaunchKernelGGL((arc_kernel128<1, 64>), dim3(ceil_div(L, 64), B), dim3(256), lds64, st, a);

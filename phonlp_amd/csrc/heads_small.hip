@@ -319,8 +319,7 @@ static int pos_head_impl(const float *enc, int ld_enc, const int32_t *sentlens, 
     // Engine 2: upos_hid on split images.  enc is split once -- straight into the enc columns of the feat image when
     // the caller wants one (pos_tail_kernel then only adds the embedding columns), else into the workspace; Whid (H
     // rows) is split per call.  E % 8 == 0 keeps the enc columns on whole 32-byte groups of the image.
-    static const bool x3_off = getenv("PHONLP_POS_X3") && atoi(getenv("PHONLP_POS_X3")) == 0;  // A/B switch
-    const bool x3 = gemm_engine() == 2 && (E % 8) == 0 && !x3_off;
+    const bool x3 = gemm_engine() == 2 && (E % 8) == 0;
     int rc;
     int presplit = 0;
     if (x3) {

@@ -763,14 +763,10 @@ int gemm_engine() {
 }
 void set_gemm_engine(int e) { g_engine = e; }
 
-// Grid size.  One block per tile by default.  PHONLP_GEMM_PERSISTENT=1 selects a persistent grid of two blocks
-// per CU walking strided tiles (+3 % when the GEMM has the chip to itself, but its static partition stalls
-// when kernels of other streams hold CUs, which is how TaskHeads.annotate_batch runs).
-static int persistent_grid(int ntiles) {
-    static const bool persistent = getenv("PHONLP_GEMM_PERSISTENT") && atoi(getenv("PHONLP_GEMM_PERSISTENT")) == 1;
-    if (!persistent || ntiles < 512) return ntiles;
-    return 512;
-}
+// Grid size: one block per tile.  (A persistent grid of two blocks per CU walking strided tiles was +3 % with the chip
+// to itself, but its static partition stalls when kernels of other streams hold CUs, which is how
+// TaskHeads.annotate_batch runs: removed.)
+static int persistent_grid(int ntiles) { return ntiles; }
 
 // `sentlens` (with L) marks the padded rows (row % L >= sentlens[row / L]).  They are written as zeros -- or, when
 // `pad_bias` is given, as act(pad_bias): that is what a following layer makes of an all-zero input row, used when
@@ -794,8 +790,7 @@ int launch_linear(const char *tag, const float *X, long ldx, const float *W, lon
         // Narrow layers (upos_clf, ner_tag_clf) are HBM-bound row streams: 128-row blocks give one block per CU at
         // B*L = 32768 (latency-bound); 32-row blocks of one wave give 4x the loads in flight (PHONLP_NARROW_BM=128: A/B).
         a.num_n = ceil_div(N, 32);
-        static const int narrow_bm = getenv("PHONLP_NARROW_BM") ? atoi(getenv("PHONLP_NARROW_BM")) : 32;
-        if (narrow_bm == 32 && M >= 4096) {
+        if (M >= 4096) {
             a.num_m = ceil_div(M, 32);
             const dim3 g(a.num_m * a.num_n, nbatch);
             if (eng) hipLaunchKernelGGL((linear_kernel<32, 32, 1, 1, 0, 1>), g, dim3(64), 0, stream, a);
@@ -808,10 +803,9 @@ int launch_linear(const char *tag, const float *X, long ldx, const float *W, lon
     } else {
         a.num_n = ceil_div(N, 128);
         const dim3 g(persistent_grid(a.num_m * a.num_n), nbatch);
-        static const bool in_regs = getenv("PHONLP_X6_IN_REGS") != nullptr;  // A/B switch: split per fragment use
-        static const bool small_tile = getenv("PHONLP_X6_TILE128") != nullptr;  // A/B switch: 128 x 128 split kernel
+        constexpr bool in_regs = false;  // (the split-per-fragment-use form of engine 1: measured behind, kept for small M)
         const dim3 g1(a.num_m * a.num_n, nbatch);
-        if (eng && !in_regs && !small_tile && M >= 1024 && K >= 8) {
+        if (eng && M >= 1024 && K >= 8) {
             static PerDeviceOnce attr_once;
     int attr_dev;
             constexpr int LDS = 2 * 3 * 384 * 32;

@@ -1080,9 +1080,7 @@ int launch_linear_f16x3(const char *tag, const void *Xp, long pitch_x, const flo
     static PerDeviceOnce attr_once;
     int attr_dev;
     if (attr_once.pending(&attr_dev)) {
-        const void *fns[] = {(const void *)linear_f16x3_dma_kernel<0, true>, (const void *)linear_f16x3_dma_kernel<1, true>,
-                             (const void *)linear_f16x3_dma_kernel<0, false>, (const void *)linear_f16x3_dma_kernel<1, false>,
-                             (const void *)linear_f16x3_dma_kernel<0, false, true>,
+        const void *fns[] = {(const void *)linear_f16x3_dma_kernel<0, false, true>,
                              (const void *)linear_f16x3_dma_kernel<1, false, true>,
                              (const void *)linear_f16x3_dma_kernel<0, true, true>,
                              (const void *)linear_f16x3_dma_kernel<1, true, true>};
@@ -1105,15 +1103,13 @@ int launch_linear_f16x3(const char *tag, const void *Xp, long pitch_x, const flo
         a.rows4 = 2;
         a.x2 = at_heads->x2; a.P = at_heads->P; a.ldx2 = at_heads->ldx2;
         a.kpc = at_heads->kpc; a.kpx = at_heads->kpx; a.nrel = at_heads->nrel;
-        a.gm = at_heads->gm;
-        static const int gm_env = getenv("PHONLP_X3_GM") ? atoi(getenv("PHONLP_X3_GM")) : 0;  // A/B: row tiles per walk group
-        if (gm_env > 0) a.gm = gm_env;
+        a.gm = at_heads->gm;  // row tiles per walk group (8 wide, 4 otherwise: flat between 4 and 16, 1 and 54 are 3-5 % behind)
     }
     if (rows4 == 1 && (sentlens || relu || ((uintptr_t)Y & 15)))
         return fail(PHONLP_ERR_SHAPE, "linear_split: the rows-by-4 output takes no activation / padding mask");
-    // the wide form (256 x 256 tile, k32 pairs): PHONLP_X3_WIDE bit 0 = the fused stage A, bit 1 = every other layer (A/B)
-    static const int wide_env = getenv("PHONLP_X3_WIDE") ? atoi(getenv("PHONLP_X3_WIDE")) : 1;
-    if ((K16 & 31) == 0 && (wide_env & (at_heads ? 1 : 2))) {
+    // the wide form (256 x 256 tile, k32 pairs) for the fused stage A only: with one workgroup per CU the W1/W2 layers'
+    // store-heavy epilogue is no longer hidden behind a second workgroup's MFMAs (2.80 against 2.75 ms per step)
+    if ((K16 & 31) == 0 && at_heads) {
         constexpr int LDS_WIDE = 2 * 512 * 128;
         static PerDeviceOnce wide_once;
         int wdev;
@@ -1126,9 +1122,8 @@ int launch_linear_f16x3(const char *tag, const void *Xp, long pitch_x, const flo
         }
         a.num_n = ceil_div(N, 256);
         // persistent form for the labels-at-heads epilogue: at least two tiles per workgroup, four pairs per tile
-        static const int persist_env = getenv("PHONLP_X3_PERSIST") ? atoi(getenv("PHONLP_X3_PERSIST")) : 1;  // A/B
         const int ntiles_w = a.num_m * a.num_n;
-        if (at_heads && at_heads->tile_ctr && persist_env && (K16 >> 5) >= 4 && ntiles_w >= 16) {
+        if (at_heads && at_heads->tile_ctr && (K16 >> 5) >= 4 && ntiles_w >= 16) {
             static PerDeviceOnce heads_once;
             static int n_cu[64];
             int hdev;
@@ -1157,23 +1152,15 @@ int launch_linear_f16x3(const char *tag, const void *Xp, long pitch_x, const flo
     }
     ProfScope ps(tag, stream);
     const dim3 g(a.num_m * a.num_n);
-    // the register-prefetch loop wins on long K (W1/W2 layers), the plain loop on short K (stage A): K16 picks
-    // (PHONLP_X3_PREFETCH=0/1 forces one form, A/B only)
-    static const int pf_env = getenv("PHONLP_X3_PREFETCH") ? atoi(getenv("PHONLP_X3_PREFETCH")) : -1;
-    const bool prefetch = pf_env >= 0 ? pf_env != 0 : K16 >= 512;
-    static const int ilv_env = getenv("PHONLP_X3_ILV") ? atoi(getenv("PHONLP_X3_ILV")) : 3;  // A/B: LDS-DMA issues between the MFMAs
-    if (!prefetch && (ilv_env & 1)) {
+    // the register-prefetch loop wins on long K (W1/W2 layers), the plain loop on short K (stage A): K16 picks; both with the
+    // LDS-DMA issues spread between the MFMAs (3-7 % on every layer over a burst at the top of the stage)
+    const bool prefetch = K16 >= 512;
+    if (!prefetch) {
         if (stage_a) hipLaunchKernelGGL((linear_f16x3_dma_kernel<1, false, true>), g, dim3(256), LDS_DMA, stream, a);
         else hipLaunchKernelGGL((linear_f16x3_dma_kernel<0, false, true>), g, dim3(256), LDS_DMA, stream, a);
-    } else if (prefetch && (ilv_env & 2)) {
+    } else {
         if (stage_a) hipLaunchKernelGGL((linear_f16x3_dma_kernel<1, true, true>), g, dim3(256), LDS_DMA, stream, a);
         else hipLaunchKernelGGL((linear_f16x3_dma_kernel<0, true, true>), g, dim3(256), LDS_DMA, stream, a);
-    } else if (prefetch) {
-        if (stage_a) hipLaunchKernelGGL((linear_f16x3_dma_kernel<1, true>), g, dim3(256), LDS_DMA, stream, a);
-        else hipLaunchKernelGGL((linear_f16x3_dma_kernel<0, true>), g, dim3(256), LDS_DMA, stream, a);
-    } else {
-        if (stage_a) hipLaunchKernelGGL((linear_f16x3_dma_kernel<1, false>), g, dim3(256), LDS_DMA, stream, a);
-        else hipLaunchKernelGGL((linear_f16x3_dma_kernel<0, false>), g, dim3(256), LDS_DMA, stream, a);
     }
     return check_launch("linear_f16x3_dma_kernel");
 }

@@ -428,10 +428,7 @@ __global__ void mst_pick_kernel(MstArgs a) {
 
 // slots per sentence of the two-phase form (candidates beyond that many share the slots round-robin)
 constexpr int kCandSlots = 4;
-static bool mst_two_phase() {
-    static const bool off = getenv("PHONLP_MST_TWO_PHASE") && atoi(getenv("PHONLP_MST_TWO_PHASE")) == 0;  // A/B switch
-    return !off;
-}
+static bool mst_two_phase() { return true; }  // long sentences' candidates side by side (one after the other: round 1's form)
 
 static size_t mst_aux_bytes(int L) { return (size_t)L * 8 * 3 + 32 + (size_t)L * 4 * 17 + (SC_COUNT + 16) * 4; }
 static bool mst_fits_lds(int L) { return (size_t)L * mst_pitch(L) * 8 + mst_aux_bytes(L) <= 160 * 1024; }
@@ -525,8 +522,7 @@ extern "C" int phonlp_mst_one_root(const float *arc, const int32_t *sentlens, in
     ProfScope ps("mst", as_stream(stream));
     const size_t regions = mst_regions(B, L);
     const size_t stack_bytes = align_up(regions * L * a.lvl_stride * sizeof(uint16_t), 256);
-    static const bool blocksync = getenv("PHONLP_MST_BLOCKSYNC") != nullptr;  // A/B: the block-synchronous kernel for every L
-    if (mst_wave_fits(L) && !blocksync) {
+    if (mst_wave_fits(L)) {
         const size_t off = mst_share_offset(B, L);
         mst_share_carve(a, (char *)ws + off);
         const bool fast = mst_fast_enabled() && mst_fast_fits(L);

@@ -460,9 +460,7 @@ int launch_mst_round(MstArgs a, hipStream_t stream) {
                 return fail(PHONLP_ERR_LAUNCH, "mst_one_root: cannot raise the dynamic LDS limit");
         attr_once.mark(attr_dev);
     }
-    static const int nt_env = getenv("PHONLP_MST_ROUND_NT") ? atoi(getenv("PHONLP_MST_ROUND_NT")) : 0;  // A/B switch
-    int threads = a.L <= 256 ? 512 : 1024;  // one thread per word; the waves beyond that speed up the row rescans
-    if (nt_env >= a.L && nt_env <= 1024 && (nt_env & 63) == 0) threads = nt_env;
+    const int threads = a.L <= 256 ? 512 : 1024;  // one thread per word; the waves beyond that speed up the row rescans
     const size_t lds = mst_round_lds(a.L);
     for (int mode = 1; mode <= 2; ++mode) {
         a.mode = mode;

@@ -226,23 +226,15 @@ class TaskHeads:
         # what the tests run
         env = os.environ.get
         self.cfg = {
-            "tagger_fused": env("PHONLP_TAGGER_FUSED", "1") == "1",  # 0: pos_head + ner_emission instead of tagger_head
-            "tagger_late": int(env("PHONLP_TAGGER_LATE", "-1")),  # tagger chain start: 0 batch start, 1 arc-done, 2 behind label W1/W2; -1 (default): 1 with the MST on the main stream (eager launches), else 2
-            "pos_fold": env("PHONLP_POS_FOLD", "1") == "1",      # scorers read [enc ; pos_dis] (K = 792) instead of [enc ; pos_emb]
-            "rows4": env("PHONLP_ROWS4", "1") != "0",            # unfused form: T in the rows-by-4 layout
-            "ones_col": env("PHONLP_ONES_COL", "1") == "1",      # unfused form: X1's ones column as a per-column bias
             # stage A fused with labels-at-heads behind the MST (T never reaches HBM): default since the round-based MST
             "label_fused": env("PHONLP_LABEL_FUSED", "1") == "1",
             # ... up to this sentence length: beyond it the MST (matrix in global memory, csrc/mst_round.hip) takes longer
             # than stage A, so the unfused form -- stage A beside the MST, labels-at-heads after it -- is shorter
-            # (B=64, L=512: 5.6 vs 6.2 ms)
+            # (B=64, L=512: 5.0 vs 5.6 ms)
             "fused_max_len": int(env("PHONLP_FUSED_MAX_LEN", "128")),
             # ragged batches whose lengths the host knows: the live words packed (no arithmetic on padding); 0 = off,
             # else the largest live fraction (percent) that is still packed
             "pack_pct": int(env("PHONLP_PACK", "90")),
-            # joined fused form: 1 = the MST continues the main stream's queue behind the arc scores and the label
-            # scorer's first layers go to a side stream (0: the MST on a side stream, the label layers on main)
-            "mst_on_main": env("PHONLP_MST_ON_MAIN", "1") == "1",
             # engine 2, sentences of up to 512 words: the arc scorers' stages A and B in one kernel, fed by the image the
             # W1/W2 layer writes (0: stage A as a GEMM of its own, stage B converting fp32 operands: the round-2 form)
             "arc_fused": env("PHONLP_ARC_FUSED", "1") == "1",
@@ -492,7 +484,7 @@ class TaskHeads:
         cfg, w = self.cfg, self.w
         if not cfg["pack_pct"] or ops.get_gemm_engine() != 2 or w.lab_Wbt_s is None:
             return None
-        if not (cfg["label_fused"] and cfg["pos_fold"] and w.arc_W12p_s is not None and cfg["tagger_fused"]):
+        if not (cfg["label_fused"] and w.arc_W12p_s is not None):
             return None
         if enc_dep.shape[1] > cfg["fused_max_len"]:
             return None
@@ -568,32 +560,23 @@ class TaskHeads:
                                                       w.upos_clf_w, w.upos_clf_b, w.emb_ner, w.ner_w_emb, w.ner_b)
                     tag = {"pos_pred": ops.unpack_rows(pos_p.view(-1), map_t, Bt * Lt).view(Bt, Lt),
                            "ner_logits": ops.unpack_rows(ner_p.view(pack[1], -1), map_t, Bt * Lt).view(Bt, Lt, -1)}
-                elif cfg["tagger_fused"]:
+                else:
                     pos_pred, ner_logits, _ = ops.tagger_head(enc_tag.contiguous(), lens_t, w.tag_Whn, w.tag_bhn,
                                                               w.upos_clf_w, w.upos_clf_b, w.emb_ner, w.ner_w_emb, w.ner_b)
                     tag = {"pos_pred": pos_pred, "ner_logits": ner_logits}
-                else:
-                    tag = self.tagger(enc_tag, lens_t)
                 ner, _ = ops.crf_viterbi(tag["ner_logits"], w.trans, lens_t)
                 tag_done = torch.cuda.Event()
                 tag_done.record(s_tag)
             return tag, ner, tag_done
 
         split = ops.get_gemm_engine() == 2 and w.lab_Wbt_s is not None
-        # the MST on the main stream's queue (joined, fused form; see below): decided here because the tagger chain's
-        # default starting point depends on it.  Tagger chain start (cfg tagger_late): 1 = when the arc scores are done,
-        # 2 = behind the label scorer's W1/W2 layer (engine 2 path only), 0 = at the start of the batch (A/B)
-        mst_main = cfg["mst_on_main"] and join and split and cfg["label_fused"] and enc_dep.shape[1] <= cfg["fused_max_len"]
-        # (under graph capture the streams become a DAG and the launch order no longer decides who reaches the CUs first:
-        # there the tagger chain behind the label layers is the better start, 2.45 against 2.58 ms per replay)
-        tl = cfg["tagger_late"] if cfg["tagger_late"] >= 0 else (
-            1 if mst_main and not torch.cuda.is_current_stream_capturing() else 2)
-        tagger_later = split and tl == 2
-        tagger_late = tl >= 1
-        if not tagger_late and not tagger_later:
-            start = torch.cuda.Event()
-            start.record(main)
-            tag, ner, tag_done = run_tagger(start)
+        # The MST on the main stream's queue (joined, fused form; see below): decided here because the tagger chain's
+        # starting point depends on it -- with the MST on main and eager launches the chain starts when the arc scores
+        # are done; otherwise (side-stream MST, or under graph capture, where the streams become a DAG and the launch
+        # order no longer decides who reaches the CUs first: 2.45 against 2.58 ms per replay) behind the label scorer's
+        # W1/W2 layer (engine 2) / at arc-done (other engines).
+        mst_main = join and split and cfg["label_fused"] and enc_dep.shape[1] <= cfg["fused_max_len"]
+        tagger_later = split and not (mst_main and not torch.cuda.is_current_stream_capturing())
         # parser chain up to the arc log-probs on the main stream
         B, Ld, D = enc_dep.shape[0], enc_dep.shape[1], enc_dep.shape[2] + w.emb_dep.shape[1]
         rows4 = fused = False
@@ -601,13 +584,12 @@ class TaskHeads:
         arcW, labW = w.arc_W12f_s, w.lab_W12f_s
         if split:  # engine 2: the large layers run on split images; the POS head's tail writes feat as one directly
             emb = w.emb_dep
-            if w.arc_W12p_s is not None and cfg["pos_fold"]:
+            if w.arc_W12p_s is not None:
                 # the embedding is folded into the scorers' weights: the "feat" image is [enc | tag probabilities]
                 emb, arcW, labW = w.emb_eye, w.arc_W12p_s, w.lab_W12p_s
                 D = enc_dep.shape[2] + emb.shape[1]
             # the arc scorers' two bilinear stages as ONE kernel on the image their first layer writes (csrc/arc_f16x3.hip)
-            arc_fused = (cfg["arc_fused"] and w.arc_W12q_s is not None and Ld <= 512 and cfg["pos_fold"]
-                         and w.arc_W12p_s is not None)
+            arc_fused = cfg["arc_fused"] and w.arc_W12q_s is not None and Ld <= 512 and w.arc_W12p_s is not None
             if pack:
                 # Live words only from here to the labels (the reference's dense layers run on PackedSequence data,
                 # annotate_model.py:155-187): every row-wise op sees ONE sentence of m_live words; the arc kernel and
@@ -647,7 +629,7 @@ class TaskHeads:
                                                 w.linearization, w.distance, False, lens_d, w.arc_b12)
         arc_done = torch.cuda.Event()
         arc_done.record(main)
-        if tagger_late and not tagger_later:
+        if not tagger_later:
             tag, ner, tag_done = run_tagger(arc_done)
         # MST beside the label scorer
         if mst_main:
@@ -684,18 +666,15 @@ class TaskHeads:
                 main.wait_event(w12_done)
                 for t in (XF, x1p, x1i):
                     t.record_stream(main)
-            rows4 = cfg["rows4"]
+            rows4 = True  # unfused form: T in the rows-by-4 layout, X1's ones column as a per-column bias
             # Fused form (stage A after the MST with the labels-at-heads contraction in its epilogue): T (1.8 GB at the
             # headline size) is neither written nor read.  It needs the heads, so it waits for the MST -- affordable since
             # the round-based decode (csrc/mst_fast.hip); the MST runs beside the label scorer's W1/W2 layer and split.
             fused = cfg["label_fused"] and Ld <= cfg["fused_max_len"]
             if fused:
                 T = x1p  # stage A runs after the MST, inside label_at_heads_fused (T never reaches memory)
-            elif rows4:
-                ones_col = w.lab_ones_col if cfg["ones_col"] else None
-                T = ops.label_stage_a_split(x1p, x1i, w.lab_Wbt_s[0], w.lab_Wbt_s[1], B, Ld, w.H, w.O, ones_col)  # T4
             else:
-                T = ops.linear_split(x1p, x1i, w.lab_Wbt_s[0], w.lab_Wbt_s[1], None, ops.kp(w.H), False, None, 0, None, 1)
+                T = ops.label_stage_a_split(x1p, x1i, w.lab_Wbt_s[0], w.lab_Wbt_s[1], B, Ld, w.H, w.O, w.lab_ones_col)  # T4
         else:
             XF, T = ops.label_project(feat, w.lab_W12f, w.lab_b12f, w.lab_Wbt, w.H, w.O, lens_d, w.lab_b12)
         if join:

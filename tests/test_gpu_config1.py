@@ -51,3 +51,23 @@ def test_config1_text_api(model, golden):
     assert [p[0] for p in pos[0]] == [w[2] for w in want]
     assert ner[0] == [w[3] for w in want]
     assert [d[0] for d in dep[0]] == [w[4] for w in want] and [d[1] for d in dep[0]] == [w[5] for w in want]
+
+
+def test_config1_mst_fast_path_rate(model, golden):
+    """How many of config 1's 100 real sentences the round-based MST hands to the reference-order kernel on the scores
+    the heads give them (the rate was only known on synthetic log-probabilities).  The gate is a margin, not
+    exactness, so ordinary float scores of any dynamic range qualify; only (near-)ties fall back."""
+    from phonlp_amd import ops
+    from phonlp_amd.compat import refresh_heads
+    z = golden("config1_sample.npz")
+    sents = [t.split(" ") for t in z["sent_text"].tolist()]
+    data = model.chunk_batches(model.process_data_parser(sents), 100)
+    tokens, first_subword, _, _, _, sentlens = model.get_batch(0, data)
+    arc, _ = model.dep_forward(tokens, first_subword, sentlens)
+    dev = torch.device("cuda:0")
+    heads, status, nfb = ops.mst_one_root_counted(torch.from_numpy(arc).to(dev),
+                                                  torch.tensor(list(sentlens), dtype=torch.int32, device=dev))
+    torch.cuda.synchronize()
+    assert (status == 0).all()
+    print(f"config 1: {int(nfb)} of {len(sents)} sentences took the reference-order fallback")
+    assert 0 <= int(nfb) <= 5
