@@ -13,12 +13,13 @@
 //            Ta is scaled by a power of two and split into f16 pieces right out of the registers;
 //   phase B  S[i][j] = sum_n Ta[i][n] X2[j][n]          (:33), chunk by chunk of 32 features: the wave writes the chunk's
 //            pieces into its own 4 KB LDS patch (eight-byte stores: four consecutive n per register group), reads them
-//            back as MFMA row fragments and multiplies them with the heads' X2 fragments (ring of three 16 KB slabs).
+//            back as MFMA row fragments and multiplies them with the heads' X2 fragments (ring of five 16 KB slabs, four in flight).
 //            Neither Ta (160 MB at the headline size) nor the fp32 first-layer features (320 MB) exist in memory.
 //   terms    unlabeled + logsigmoid(lin sign(j - i)) - log((|j - i| - 1 - softplus(dist))^2 / 2 + 1), in the
-//            reference's order (:192-208), accumulated in registers over the three scorers; diagonal -inf (:210-211).
-//   softmax  over ALL L head columns, padding included (:214): a lane holds four columns of sixteen rows; maximum and
-//            sum across the 32 lanes of a half-wave by shuffles; 128-byte row segments stored.
+//            reference's order (:192-208), added scorer by scorer into the output rows (an L2-resident running sum: the
+//            registers cannot hold three scorers' accumulators); diagonal -inf (:210-211).
+//   softmax  over ALL L head columns, padding included (:214), on the finished rows: four lanes per row (L <= 128) or a
+//            wavefront per row (longer sentences: head columns in groups of 128, NJG trips of phase B per scorer).
 //
 // Before: stage A as one batched GEMM on engine 1 (0.21 ms at B=256, L=128) + stage B with both fp32 operands split
 // into bf16 pieces inside the kernel (0.16 ms, matrix pipe busy 0.16: ~360 conversion instructions per 24 MFMAs).
