@@ -409,7 +409,7 @@ extern "C" int phonlp_tagger_head(const float *enc, int ld_enc, const int32_t *s
         const int K16e = (E + 15) / 16 * 16;
         rc = launch_split_rows2(enc, ld_enc, M, encp, 0, enci, Whn, E, N, whp, whi, E, st);
         if (rc) return rc;
-        rc = launch_linear_f16x3("linear:upos_hid", encp, 4L * K16e, enci, whp, 4L * K16e, whi, bhn, hid, HN, M, N, K16e, -H,
+        rc = launch_linear_f16x3("linear:tagger_hid", encp, 4L * K16e, enci, whp, 4L * K16e, whi, bhn, hid, HN, M, N, K16e, -H,
                                  sentlens, L, st, nullptr);
     } else {
         rc = launch_linear("linear:upos_hid", enc, ld_enc, Whn, E, bhn, hid, HN, M, N, E, -H, sentlens, L, st);

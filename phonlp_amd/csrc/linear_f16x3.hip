@@ -217,6 +217,128 @@ __device__ __forceinline__ void at_heads_epilogue(f32x16 (&acc)[TM][TN], const L
     }
 }
 
+// Transposed dense-layer epilogue (persistent wide kernel, EPI 1 / 2): the product is taken with the WEIGHT image as the
+// row operand and the words' image as the column operand, as for the labels-at-heads above, so an accumulator lane holds
+// ONE word and four groups of four CONSECUTIVE output features: bias / ReLU / padding mask are applied in registers.  A
+// 32 x 32 accumulator tile is then 128 contiguous bytes of each of 32 words' rows, both as fp32 (IMAGE = false) and as f16
+// pieces of the split image (IMAGE = true; LinearArgs::img, scale from the bound as in linear_epilogue) -- but spread over
+// a word's two lanes and four register groups.  Stored from there (8 / 16 bytes per lane, 32 different lines per
+// instruction) the stores cost a third of the layer: the CU's path to L2 takes a request per LINE touched, whatever it
+// carries (halving the bytes: -3 %; an L2-resident target: still 60 % of the cost).  So the tile goes through the wave's
+// own 4 KB of LDS (the 32 KB the two pair buffers leave free; chunk c of word r at slot c ^ ((r >> 1) & 7): two-way on the
+// writes, conflict-free on the reads) and leaves as FULL lines, eight lanes a word: an eighth of the requests.
+// a.M = output features (a.row_scale, a.bias, a.pad_bias per feature; a multiple of 4 -- 8 for the image --, the three
+// arrays 16-byte aligned: the launcher checks), a.N = words (a.col_scale per word, a.sentlens / a.L their padding mask),
+// Y[word * ldy + feature].
+template <int TM, int TN, bool IMAGE>
+__device__ __forceinline__ void transposed_epilogue(f32x16 (&acc)[TM][TN], const LinearArgs &a, int m0, int n0, int wm,
+                                                    int wn, int lane, unsigned char *lds_base, unsigned patch_ofs) {
+    // (opaque: everything lane-dependent below is derived HERE, per tile -- hoisted out of the persistent kernel's tile loop
+    // it would be spilled across the main loop, and a scratch reload waits for every vector-memory operation in flight.
+    // The patch is addressed as an OFFSET into the kernel's LDS array: a pointer through the asm would lose its address
+    // space and turn the ds_ accesses into flat ones.)
+    asm volatile("" : "+v"(lane), "+v"(patch_ofs));
+    unsigned char *patch = lds_base + patch_ofs;
+    const int half = lane >> 5, l32 = lane & 31;
+    int word[TN];
+    float cs[TN], isc[TN];
+    bool live[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        word[j] = n0 + (wn * TN + j) * 32 + l32;
+        const bool wv = word[j] < a.N;
+        cs[j] = wv ? a.col_scale[word[j]] : 0.f;
+        live[j] = wv && (!a.sentlens || (word[j] % a.L) < a.sentlens[word[j] / a.L]);
+        isc[j] = 1.f;
+        if constexpr (IMAGE) {
+            float inv;
+            image_scale_of_bound(a.img_c * cs[j] * 32768.f + a.img_b, isc[j], inv);
+            if (wv && m0 == 0 && wm == 0 && half == 0) a.img_inv[word[j]] = inv;
+        }
+    }
+    const int relu_n = a.relu > 0 ? INT_MAX : -a.relu;
+    const bool vec_ok = IMAGE || (((a.ldy & 3) == 0) && (((uintptr_t)a.Y & 15) == 0));
+    unsigned char *wr_row = patch + l32 * 128;
+    const int wsw = (l32 >> 1) & 7;
+    // read side: lane = (word 8q + (lane >> 3) of the tile, 16-byte piece lane & 7 of its 128 bytes)
+    const int rw = lane >> 3, rk = lane & 7;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int f0 = m0 + (wm * TM + i) * 32;  // the tile's first feature
+        if (f0 >= a.M) continue;                 // wave-uniform
+        float4 rs[4], bv[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int f = f0 + 8 * g + 4 * half;  // the group's first feature (a.M % 4 == 0)
+            const int fc = f < a.M ? f : 0;
+            rs[g] = *reinterpret_cast<const float4 *>(a.row_scale + fc);
+            bv[g] = a.bias ? *reinterpret_cast<const float4 *>(a.bias + fc) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int f = f0 + 8 * g + 4 * half;
+                float4 lo;  // ReLU as a lower clamp: 0 where it applies, -inf elsewhere
+                lo.x = (a.relu && f < relu_n) ? 0.f : -INFINITY;
+                lo.y = (a.relu && f + 1 < relu_n) ? 0.f : -INFINITY;
+                lo.z = (a.relu && f + 2 < relu_n) ? 0.f : -INFINITY;
+                lo.w = (a.relu && f + 3 < relu_n) ? 0.f : -INFINITY;
+                float4 v;  // (acc * 2^-ka) * 2^-kb: exact, in the order of linear_epilogue
+                v.x = fmaxf(acc[i][j][4 * g + 0] * cs[j] * rs[g].x + bv[g].x, lo.x);
+                v.y = fmaxf(acc[i][j][4 * g + 1] * cs[j] * rs[g].y + bv[g].y, lo.y);
+                v.z = fmaxf(acc[i][j][4 * g + 2] * cs[j] * rs[g].z + bv[g].z, lo.z);
+                v.w = fmaxf(acc[i][j][4 * g + 3] * cs[j] * rs[g].w + bv[g].w, lo.w);
+                if (!live[j]) {  // a padded word: act(pad_bias), or zeros
+                    v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (a.pad_bias) {
+                        const float4 pb = *reinterpret_cast<const float4 *>(a.pad_bias + (f < a.M ? f : 0));
+                        v.x = fmaxf(pb.x, lo.x); v.y = fmaxf(pb.y, lo.y); v.z = fmaxf(pb.z, lo.z); v.w = fmaxf(pb.w, lo.w);
+                    }
+                }
+                if constexpr (IMAGE) {  // chunk 2g = h[8], 2g + 1 = l[8] of features 8g .. 8g + 7; this lane's four at byte 8 half
+                    const float s4[4] = {v.x * isc[j], v.y * isc[j], v.z * isc[j], v.w * isc[j]};  // exact (powers of two)
+                    img_f16x4 h, l;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        h[e] = (_Float16)s4[e];
+                        l[e] = (_Float16)(s4[e] - (float)h[e]);
+                    }
+                    *reinterpret_cast<img_f16x4 *>(wr_row + (((2 * g) ^ wsw) << 4) + 8 * half) = h;
+                    *reinterpret_cast<img_f16x4 *>(wr_row + (((2 * g + 1) ^ wsw) << 4) + 8 * half) = l;
+                } else {  // chunk 2g + half = features 8g + 4 half .. + 3
+                    *reinterpret_cast<float4 *>(wr_row + (((2 * g + half) ^ wsw) << 4)) = v;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            // piece rk of a word's 128 bytes: image -- features 8 (rk >> 1) .. + 7 (h or l); fp32 -- features 4 rk .. + 3
+            const bool piece_ok = f0 + (IMAGE ? 8 * (rk >> 1) : 4 * rk) < a.M;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = 8 * q + rw;
+                const int wd = n0 + (wn * TN + j) * 32 + r;
+                const u32x4 d = *reinterpret_cast<const u32x4 *>(patch + r * 128 + ((rk ^ ((r >> 1) & 7)) << 4));
+                if (wd >= a.N || !piece_ok) continue;
+#ifdef PHONLP_ABLATION
+                if (a.dbg == 1 && d[0] != 0x12345u) continue;
+#endif
+                if constexpr (IMAGE) {
+                    *reinterpret_cast<u32x4 *>(a.img + (long)wd * a.img_pitch + (long)f0 * 4 + rk * 16) = d;
+                } else {
+                    float *y = a.Y + (long)wd * a.ldy + f0 + 4 * rk;
+                    if (vec_ok) {
+                        *reinterpret_cast<u32x4 *>(y) = d;
+                    } else {
+                        y[0] = __uint_as_float(d[0]); y[1] = __uint_as_float(d[1]);
+                        y[2] = __uint_as_float(d[2]); y[3] = __uint_as_float(d[3]);
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+    }
+}
+
 // hrow[m] = row of the head's features for word m = (b, i), 1 <= i < sentlens[b]; -1 elsewhere (ROOT, padding); and
 // x2t[d2 / 4][m][d2 % 4] = x2[hrow[m]][d2] (0 where there is no head; kpx % 4 == 0): the head-side features gathered
 // through the decoded heads, transposed and interleaved by four so that the epilogue above reads a word's four
@@ -867,7 +989,8 @@ __device__ __forceinline__ void wide_tile_origin(const LinearArgs &a, int t, int
 // read its fragments -- those registers are the epilogue's -- and the next tile's first fragments are read behind the
 // epilogue.  Needs a.K / 32 >= 4.  No waiting on other workgroups anywhere: a workgroup that draws a number past its
 // chunk leaves.
-__global__ __launch_bounds__(512, 1) void linear_f16x3_wide_heads_kernel(LinearArgs a) {
+template <int EPI>
+__global__ __launch_bounds__(512, 1) void linear_f16x3_wide_persist_kernel(LinearArgs a) {
     constexpr int BM = 256, BN = 256, WN = 4, TM = 4, TN = 2;
     constexpr int ROWS = BM + BN, PBUF = ROWS * 128;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -880,10 +1003,17 @@ __global__ __launch_bounds__(512, 1) void linear_f16x3_wide_heads_kernel(LinearA
     const int ntiles = a.num_m * a.num_n, q8 = ntiles >> 3, r8 = ntiles & 7;
     const int chunk0 = xg < r8 ? xg * (q8 + 1) : r8 * (q8 + 1) + (xg - r8) * q8;  // this XCD's tiles: chunk0 .. chunk0 + chunkn
     const int chunkn = q8 + (xg < r8 ? 1 : 0);
-    if (tid == 0) s_next = atomicAdd(a.tile_ctr + xg, 1);
-    __syncthreads();
-    const int first = __builtin_amdgcn_readfirstlane(s_next);
+    // EPI 0: tiles drawn from the XCD's counter; EPI 1 / 2 (no counter to zero: these layers are launched from several
+    // streams at once): workgroup jl of the XCD takes tiles jl, jl + stride, ... of the chunk
+    const int stride = gridDim.x >> 3;
+    int first = blockIdx.x >> 3;
+    if constexpr (EPI == 0) {
+        if (tid == 0) s_next = atomicAdd(a.tile_ctr + xg, 1);
+        __syncthreads();
+        first = __builtin_amdgcn_readfirstlane(s_next);
+    }
     if (first >= chunkn) return;
+    int cur_tile = first;
     int m0, n0;
     wide_tile_origin(a, chunk0 + first, m0, n0);
 
@@ -960,18 +1090,31 @@ __global__ __launch_bounds__(512, 1) void linear_f16x3_wide_heads_kernel(LinearA
     // into this pair's buffer between the last eight MFMAs (the barrier is what frees the buffer); 2 = the same if `flag`
     // (wave-uniform: the branches hold nothing but the issue -- two code paths with MFMAs in them made hipcc shuffle the
     // accumulators at the merge and spill a thousand registers); 0 = none.
+    // (EPI 1 / 2: the row operand is the weight image, so the two small terms are taken in the order ah.bl, al.bh -- the
+    // words' low pieces first, as the 256 x 128 kernel does with the words as rows: products commute exactly and k runs the
+    // same way, so both kernels give the same bits and a sentence's results do not depend on which of them a batch size picks)
     auto body = [&](int pb, long so, auto join, auto loads, bool flag) {
         constexpr int JOIN = decltype(join)::value, LOADS = decltype(loads)::value;
         const unsigned char *buf = lds + pb * PBUF;
-        PHONLP_X3_ROUND(F, al, bh)
-        PHONLP_X3_ROUND(F, ah, bl)
+        if constexpr (EPI == 0) {
+            PHONLP_X3_ROUND(F, al, bh)
+            PHONLP_X3_ROUND(F, ah, bl)
+        } else {
+            PHONLP_X3_ROUND(F, ah, bl)
+            PHONLP_X3_ROUND(F, al, bh)
+        }
         pin();
         read_frags(buf, 1, G);
         pin();
         PHONLP_X3_ROUND(F, ah, bh)
         pin();
-        PHONLP_X3_ROUND(G, al, bh)
-        PHONLP_X3_ROUND(G, ah, bl)
+        if constexpr (EPI == 0) {
+            PHONLP_X3_ROUND(G, al, bh)
+            PHONLP_X3_ROUND(G, ah, bl)
+        } else {
+            PHONLP_X3_ROUND(G, ah, bl)
+            PHONLP_X3_ROUND(G, al, bh)
+        }
         pin();
         if constexpr (JOIN == 2) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1017,15 +1160,21 @@ __global__ __launch_bounds__(512, 1) void linear_f16x3_wide_heads_kernel(LinearA
     int pb = 0;
     for (;;) {
         int drawn = 0;  // the next tile's number: drawn now, needed npair - 3 pairs from here
-        if (tid == 0) drawn = atomicAdd(a.tile_ctr + xg, 1);
+        if constexpr (EPI == 0) {
+            if (tid == 0) drawn = atomicAdd(a.tile_ctr + xg, 1);
+        }
         for (int p = 0; p + 3 < npair; ++p) {
             body(pb, (long)(p + 2) * 128, C2{}, C1{}, true);
             pb ^= 1;
         }
-        if (tid == 0) s_next = drawn;
+        if constexpr (EPI == 0) {
+            if (tid == 0) s_next = drawn;
+        }
         body(pb, (long)(npair - 1) * 128, C2{}, C1{}, true);  // the tile's last loads; its barrier publishes s_next
         pb ^= 1;
-        const int nxt = __builtin_amdgcn_readfirstlane(s_next);
+        int nxt = cur_tile + stride;
+        if constexpr (EPI == 0) nxt = __builtin_amdgcn_readfirstlane(s_next);
+        cur_tile = nxt;
         const bool has_next = nxt < chunkn;
         int m1 = m0, n1 = n0;
         if (has_next) {
@@ -1048,7 +1197,10 @@ __global__ __launch_bounds__(512, 1) void linear_f16x3_wide_heads_kernel(LinearA
             if (t == 1234.5f) a.P[tid] = t;
         } else
 #endif
-        at_heads_epilogue<TM, TN>(acc, a, m0, n0, wm, wn, lane);
+        {
+            if constexpr (EPI == 0) at_heads_epilogue<TM, TN>(acc, a, m0, n0, wm, wn, lane);
+            else transposed_epilogue<TM, TN, EPI == 1>(acc, a, m0, n0, wm, wn, lane, lds, 2u * PBUF + wave * 4096u);
+        }
         if (!has_next) break;
         zero_acc();
         m0 = m1;
@@ -1107,10 +1259,53 @@ int launch_linear_f16x3(const char *tag, const void *Xp, long pitch_x, const flo
     }
     if (rows4 == 1 && (sentlens || relu || ((uintptr_t)Y & 15)))
         return fail(PHONLP_ERR_SHAPE, "linear_split: the rows-by-4 output takes no activation / padding mask");
-    // the wide form (256 x 256 tile, k32 pairs) for the fused stage A only: with one workgroup per CU the W1/W2 layers'
-    // store-heavy epilogue is no longer hidden behind a second workgroup's MFMAs (2.80 against 2.75 ms per step)
+    constexpr int LDS_WIDE = 2 * 512 * 128, LDS_WIDE_T = LDS_WIDE + 8 * 4096;  // + the transposed epilogue's patch per wave
+    // Persistent wide kernels (256 x 256 tile, k32 pairs, one workgroup per CU): attributes and the CU count, once per device
+    static PerDeviceOnce persist_once;
+    static int n_cu[64];
+    auto persist_cus = [&]() -> int {
+        int pdev;
+        if (persist_once.pending(&pdev)) {
+            int cus = 0;
+            const void *pf[] = {(const void *)linear_f16x3_wide_persist_kernel<0>, (const void *)linear_f16x3_wide_persist_kernel<1>,
+                                (const void *)linear_f16x3_wide_persist_kernel<2>};
+            for (int k = 0; k < 3; ++k)
+                if (hipFuncSetAttribute(pf[k], hipFuncAttributeMaxDynamicSharedMemorySize, k ? LDS_WIDE_T : LDS_WIDE) != hipSuccess)
+                    return -1;
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, pdev) != hipSuccess || cus < 8) return -1;
+            n_cu[pdev & 63] = cus;
+            persist_once.mark(pdev);
+        }
+        int cur_dev = 0;
+        (void)hipGetDevice(&cur_dev);
+        return n_cu[cur_dev & 63] & ~7;
+    };
+    // The plain layers at large sizes (W1/W2 of the scorers, upos_hid) on the persistent wide kernel, taken TRANSPOSED (row
+    // operand = the weight image, column operand = the words): the accumulator lane then holds four consecutive features of
+    // ONE word, so the epilogue stores 16-byte (fp32 rows) or 8-byte (split image) pieces straight from the registers -- the
+    // row-major epilogue's LDS transposition was what made the wide tile lose on these layers (one workgroup per CU: nothing
+    // hides it).  Same bits as the 256 x 128 kernel below (see the kernel), which keeps the small products and the two
+    // layers the step runs BESIDE the MST decode (label W1/W2, the tagger's hidden layer): its 72 KB workgroups share a CU
+    // with a decode's 86 KB, this kernel's 128 KB would wait for the decodes to leave (label W1/W2 0.32 -> 0.53 ms).
+    const bool beside_decode = tag && (!strcmp(tag, "linear:label_w12") || !strcmp(tag, "linear:tagger_hid"));
+    if (!beside_decode && !rows4 && !at_heads && (K16 & 31) == 0 && (K16 >> 5) >= 4 && (N & 3) == 0 && !((uintptr_t)w_inv & 15) &&
+        !((uintptr_t)bias & 15) && !((uintptr_t)pad_bias & 15) && (long)ceil_div(N, 256) * ceil_div(M, 256) >= 64) {
+        const int cap = persist_cus();
+        if (cap < 0) return fail(PHONLP_ERR_LAUNCH, "linear_split: cannot set up the persistent wide kernel");
+        LinearArgs t = a;
+        t.X = reinterpret_cast<const float *>(Wp); t.ldx = pitch_w; t.M = N; t.row_scale = w_inv;
+        t.W = reinterpret_cast<const float *>(Xp); t.ldw = pitch_x; t.N = M; t.col_scale = x_inv;
+        t.num_m = ceil_div(N, 256); t.num_n = ceil_div(M, 256);
+        t.gm = t.num_m <= 16 ? t.num_m : 8;  // all of a word tile's feature tiles in one group of the walk
+        const int ntiles_t = t.num_m * t.num_n, want = ntiles_t & ~7;
+        ProfScope pst(tag, stream);
+        const dim3 gt(want < cap ? want : cap);
+        if (image) hipLaunchKernelGGL(linear_f16x3_wide_persist_kernel<1>, gt, dim3(512), LDS_WIDE_T, stream, t);
+        else hipLaunchKernelGGL(linear_f16x3_wide_persist_kernel<2>, gt, dim3(512), LDS_WIDE_T, stream, t);
+        return check_launch("linear_f16x3_wide_persist_kernel");
+    }
+    // the wide form for the fused stage A (its epilogue is light)
     if ((K16 & 31) == 0 && at_heads) {
-        constexpr int LDS_WIDE = 2 * 512 * 128;
         static PerDeviceOnce wide_once;
         int wdev;
         if (wide_once.pending(&wdev)) {
@@ -1123,26 +1318,13 @@ int launch_linear_f16x3(const char *tag, const void *Xp, long pitch_x, const flo
         a.num_n = ceil_div(N, 256);
         // persistent form for the labels-at-heads epilogue: at least two tiles per workgroup, four pairs per tile
         const int ntiles_w = a.num_m * a.num_n;
-        if (at_heads && at_heads->tile_ctr && (K16 >> 5) >= 4 && ntiles_w >= 16) {
-            static PerDeviceOnce heads_once;
-            static int n_cu[64];
-            int hdev;
-            if (heads_once.pending(&hdev)) {
-                int cus = 0;
-                if (hipFuncSetAttribute((const void *)linear_f16x3_wide_heads_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        LDS_WIDE) != hipSuccess ||
-                    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, hdev) != hipSuccess || cus < 8)
-                    return fail(PHONLP_ERR_LAUNCH, "linear_split: cannot set up the persistent stage A");
-                n_cu[hdev & 63] = cus;
-                heads_once.mark(hdev);
-            }
-            int cur_dev = 0;
-            (void)hipGetDevice(&cur_dev);
-            const int cap = n_cu[cur_dev & 63] & ~7, want = (ntiles_w / 2) & ~7;
+        if (at_heads->tile_ctr && (K16 >> 5) >= 4 && ntiles_w >= 16) {
+            const int cap = persist_cus(), want = (ntiles_w / 2) & ~7;
+            if (cap < 0) return fail(PHONLP_ERR_LAUNCH, "linear_split: cannot set up the persistent stage A");
             a.tile_ctr = at_heads->tile_ctr;
             ProfScope psh(tag, stream);
-            hipLaunchKernelGGL(linear_f16x3_wide_heads_kernel, dim3(want < cap ? want : cap), dim3(512), LDS_WIDE, stream, a);
-            return check_launch("linear_f16x3_wide_heads_kernel");
+            hipLaunchKernelGGL(linear_f16x3_wide_persist_kernel<0>, dim3(want < cap ? want : cap), dim3(512), LDS_WIDE, stream, a);
+            return check_launch("linear_f16x3_wide_persist_kernel");
         }
         ProfScope psw(tag, stream);
         const dim3 gw(a.num_m * a.num_n);

@@ -17,8 +17,8 @@ from phonlp_amd.profile import KernelTimer
 dev = torch.device("cuda:0")
 w = HeadWeights.from_state_dict(S.make_state_dict(), dev)
 res = []
-for B in (256, 1):
-    L = 128
+shapes = [tuple(int(v) for v in t.split("x")) for t in os.environ.get("ARC_SHAPES", "256x128,1x128").split(",")]
+for B, L in shapes:
     M = B * L
     feat = torch.randn(M, 792, device=dev)
     fp, fi = ops.split_rows(feat)
@@ -31,7 +31,7 @@ for B in (256, 1):
     with KernelTimer(256) as kt:
         for _ in range(10): run()
         torch.cuda.synchronize()
-    res.append(f"B={B}: {kt.stats['arc_fused'][1]*1e3:.1f} us (min {kt.stats['arc_fused'][2]*1e3:.1f})")
+    res.append(f"B={B} L={L}: {kt.stats['arc_fused'][1]*1e3:.1f} us (min {kt.stats['arc_fused'][2]*1e3:.1f})")
     if os.environ.get("ARC_STAMPS"):  # a -DARC_STAMPS build: cycle stamps of block 0
         dbg = torch.zeros(16, dtype=torch.int64, device=dev)
         os.environ["PHONLP_ARC_DBG"] = str(dbg.data_ptr())
