@@ -262,39 +262,55 @@ __device__ __forceinline__ void transposed_epilogue(f32x16 (&acc)[TM][TN], const
     const int wsw = (l32 >> 1) & 7;
     // read side: lane = (word 8q + (lane >> 3) of the tile, 16-byte piece lane & 7 of its 128 bytes)
     const int rw = lane >> 3, rk = lane & 7;
+    // Per-feature scales, biases and padding values of the wave's TM * 32 features: ONE load per lane and array at the top
+    // (lane t holds feature t, a second register features 64 ..), handed to the lanes that need them by ds_bpermute.  Loads
+    // inside the loop would sit behind this tile's stores in the in-order vector-memory queue: waiting for one would mean
+    // waiting for those stores' acknowledgements (four stalls of a microsecond per tile); hoisted as float4 per group they
+    // spill.
+    static_assert(TM * 32 == 128, "two registers of 64 features");
+    const int fw = m0 + wm * (TM * 32);
+    const int fa = fw + lane < a.M ? fw + lane : a.M - 1, fb = fw + 64 + lane < a.M ? fw + 64 + lane : a.M - 1;
+    float rsA = a.row_scale[fa], rsB = a.row_scale[fb];
+    float bA = 0.f, bB = 0.f, pA = 0.f, pB = 0.f;
+    if (a.bias) { bA = a.bias[fa]; bB = a.bias[fb]; }
+    if (a.pad_bias) { pA = a.pad_bias[fa]; pB = a.pad_bias[fb]; }
+    // (waited for HERE, and handed on as the asm's results: the compiler's own wait for a loaded register would be placed at its
+    // first use inside the loop as vmcnt(n) counted over ALL vector-memory operations, this tile's stores included)
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(rsA), "+v"(rsB), "+v"(bA), "+v"(bB), "+v"(pA), "+v"(pB));
+    static_assert(TN == 2, "two column tiles per wave");
+    asm volatile("" : "+v"(cs[0]), "+v"(cs[1]));
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        const int f0 = m0 + (wm * TM + i) * 32;  // the tile's first feature
-        if (f0 >= a.M) continue;                 // wave-uniform
-        float4 rs[4], bv[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int f = f0 + 8 * g + 4 * half;  // the group's first feature (a.M % 4 == 0)
-            const int fc = f < a.M ? f : 0;
-            rs[g] = *reinterpret_cast<const float4 *>(a.row_scale + fc);
-            bv[g] = a.bias ? *reinterpret_cast<const float4 *>(a.bias + fc) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        const int f0 = __builtin_amdgcn_readfirstlane(m0 + (wm * TM + i) * 32);  // the tile's first feature
+        if (f0 >= a.M) continue;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int f = f0 + 8 * g + 4 * half;
+                const int t = 32 * (i & 1) + 8 * g + 4 * half;  // source lane of the group's first feature
+                const float rv = i < 2 ? rsA : rsB, bb = i < 2 ? bA : bB;
+                const float4 rs1 = make_float4(__shfl(rv, t), __shfl(rv, t + 1), __shfl(rv, t + 2), __shfl(rv, t + 3));
+                const float4 bv1 = make_float4(__shfl(bb, t), __shfl(bb, t + 1), __shfl(bb, t + 2), __shfl(bb, t + 3));
                 float4 lo;  // ReLU as a lower clamp: 0 where it applies, -inf elsewhere
                 lo.x = (a.relu && f < relu_n) ? 0.f : -INFINITY;
                 lo.y = (a.relu && f + 1 < relu_n) ? 0.f : -INFINITY;
                 lo.z = (a.relu && f + 2 < relu_n) ? 0.f : -INFINITY;
                 lo.w = (a.relu && f + 3 < relu_n) ? 0.f : -INFINITY;
                 float4 v;  // (acc * 2^-ka) * 2^-kb: exact, in the order of linear_epilogue
-                v.x = fmaxf(acc[i][j][4 * g + 0] * cs[j] * rs[g].x + bv[g].x, lo.x);
-                v.y = fmaxf(acc[i][j][4 * g + 1] * cs[j] * rs[g].y + bv[g].y, lo.y);
-                v.z = fmaxf(acc[i][j][4 * g + 2] * cs[j] * rs[g].z + bv[g].z, lo.z);
-                v.w = fmaxf(acc[i][j][4 * g + 3] * cs[j] * rs[g].w + bv[g].w, lo.w);
-                if (!live[j]) {  // a padded word: act(pad_bias), or zeros
-                    v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (a.pad_bias) {
-                        const float4 pb = *reinterpret_cast<const float4 *>(a.pad_bias + (f < a.M ? f : 0));
-                        v.x = fmaxf(pb.x, lo.x); v.y = fmaxf(pb.y, lo.y); v.z = fmaxf(pb.z, lo.z); v.w = fmaxf(pb.w, lo.w);
+                v.x = fmaxf(acc[i][j][4 * g + 0] * cs[j] * rs1.x + bv1.x, lo.x);
+                v.y = fmaxf(acc[i][j][4 * g + 1] * cs[j] * rs1.y + bv1.y, lo.y);
+                v.z = fmaxf(acc[i][j][4 * g + 2] * cs[j] * rs1.z + bv1.z, lo.z);
+                v.w = fmaxf(acc[i][j][4 * g + 3] * cs[j] * rs1.w + bv1.w, lo.w);
+                if (a.sentlens) {  // (uniform) a padded word: act(pad_bias), or zeros
+                    const float pp = i < 2 ? pA : pB;
+                    const float4 pb = make_float4(__shfl(pp, t), __shfl(pp, t + 1), __shfl(pp, t + 2), __shfl(pp, t + 3));
+                    if (!live[j]) {
+                        v = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (a.pad_bias) { v.x = fmaxf(pb.x, lo.x); v.y = fmaxf(pb.y, lo.y); v.z = fmaxf(pb.z, lo.z); v.w = fmaxf(pb.w, lo.w); }
                     }
+                } else if (!live[j]) {
+                    v = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
                 if constexpr (IMAGE) {  // chunk 2g = h[8], 2g + 1 = l[8] of features 8g .. 8g + 7; this lane's four at byte 8 half
                     const float s4[4] = {v.x * isc[j], v.y * isc[j], v.z * isc[j], v.w * isc[j]};  // exact (powers of two)
@@ -313,24 +329,28 @@ __device__ __forceinline__ void transposed_epilogue(f32x16 (&acc)[TM][TN], const
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             // piece rk of a word's 128 bytes: image -- features 8 (rk >> 1) .. + 7 (h or l); fp32 -- features 4 rk .. + 3
             const bool piece_ok = f0 + (IMAGE ? 8 * (rk >> 1) : 4 * rk) < a.M;
+            u32x4 d[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int r = 8 * q + rw;
-                const int wd = n0 + (wn * TN + j) * 32 + r;
-                const u32x4 d = *reinterpret_cast<const u32x4 *>(patch + r * 128 + ((rk ^ ((r >> 1) & 7)) << 4));
+                d[q] = *reinterpret_cast<const u32x4 *>(patch + r * 128 + ((rk ^ ((r >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int wd = n0 + (wn * TN + j) * 32 + 8 * q + rw;
                 if (wd >= a.N || !piece_ok) continue;
 #ifdef PHONLP_ABLATION
-                if (a.dbg == 1 && d[0] != 0x12345u) continue;
+                if (a.dbg == 1 && d[q][0] != 0x12345u) continue;
 #endif
                 if constexpr (IMAGE) {
-                    *reinterpret_cast<u32x4 *>(a.img + (long)wd * a.img_pitch + (long)f0 * 4 + rk * 16) = d;
+                    *reinterpret_cast<u32x4 *>(a.img + (long)wd * a.img_pitch + (long)f0 * 4 + rk * 16) = d[q];
                 } else {
                     float *y = a.Y + (long)wd * a.ldy + f0 + 4 * rk;
                     if (vec_ok) {
-                        *reinterpret_cast<u32x4 *>(y) = d;
+                        *reinterpret_cast<u32x4 *>(y) = d[q];
                     } else {
-                        y[0] = __uint_as_float(d[0]); y[1] = __uint_as_float(d[1]);
-                        y[2] = __uint_as_float(d[2]); y[3] = __uint_as_float(d[3]);
+                        y[0] = __uint_as_float(d[q][0]); y[1] = __uint_as_float(d[q][1]);
+                        y[2] = __uint_as_float(d[q][2]); y[3] = __uint_as_float(d[q][3]);
                     }
                 }
             }
