@@ -489,6 +489,12 @@ __device__ __forceinline__ void lds_dma16(const unsigned char *gptr, unsigned ld
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_addr), "v"(gptr) : "memory", "m0");
 }
 
+// the same with a uniform (SGPR) base and a 32-bit byte offset per lane: half the address registers, and a uniform term
+// (the k offset of a pair) is added on the scalar unit
+__device__ __forceinline__ void lds_dma16_s(const unsigned char *sbase, unsigned voff, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(sbase) : "memory", "m0");
+}
+
 template <int TAG, bool PREFETCH, bool ILV = false>
 __global__ __launch_bounds__(256, 2) void linear_f16x3_dma_kernel(LinearArgs a) {
     constexpr int BM = 256, BN = 128, WM = 2, WN = 2, TM = 4, TN = 2, NBUF = 3;
@@ -1232,6 +1238,292 @@ __global__ __launch_bounds__(512, 1) void linear_f16x3_wide_persist_kernel(Linea
 #undef PHONLP_X3_ROUND
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The persistent wide kernel for the labels-at-heads epilogue on v_mfma_f32_16x16x32_f16.  Same tile (256 x 256, eight
+// waves of 128 x 64, k32 pairs, two pair buffers, tiles drawn per XCD), same three products per operand pair; what
+// changes is the instruction shape: one MFMA takes a whole k32 pair of a 16 x 16 accumulator (four passes) instead of
+// a k16 stage of a 32 x 32 one (eight).  MI355X_MICROARCH.md measures 1.12-1.15 x the FLOP/s for this shape at the clock
+// the chip holds under MFMA load, at equal cycles per FLOP and equal LDS traffic (a fragment is 16 rows x 32 k instead
+// of 32 rows x 16 k: 24 ds_read_b128 per pair and wave either way).
+//
+// Fragment of lane l: row l & 15, k-group g = l >> 4 (k = 8g .. 8g + 7 of the pair), pieces h and l: two 16-byte chunks
+// of the row's 128 bytes.  LDS slot of chunk (g, piece) of row R: (piece + {0, 6, 2, 4}[g]) ^ ((R >> 1) & 7) -- the
+// hardware serves a ds_read_b128 sixteen lanes at a time, lanes {0-3, 12-15, 20-27} and {4-11, 16-19, 28-31} of each
+// half-wave, i.e. eight rows with k-group g and eight with g + 1: with the chunk numbers of g and g + 1 differing by 6
+// every such group covers all 64 banks once (SQ_LDS_BANK_CONFLICT = 0, tools/pmc_fused.sh).  The DMA side applies
+// the mapping on the global addresses as before.
+//
+// Schedule of a pair (ah, al: row fragments of the wave's eight 16-row tiles; bh, bl: of its four column tiles; 96
+// registers as before): read bh | rows 0-3: ah.bl | read rows 4-7 | rows 0-3: al.bh, ah.bh | rows 4-7: ah.bl, al.bh |
+// wait for the next pair + barrier | read the next pair's rows 0-3 and bl | rows 4-7: ah.bh with the eight LDS-DMA
+// issues of the pair after next between its MFMAs.  Every accumulator takes its three products in the same order
+// (ah.bl, al.bh, ah.bh); results differ from the 32 x 32 kernels' in the last bits (the order inside a k32 sum).
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+#define PHONLP_F16_MFMA16(A, B, C) \
+    __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B), C, 0, 0, 0)
+
+// labels-at-heads epilogue in the 16 x 16 accumulator layout: a lane holds ONE word (column l & 15) and four consecutive
+// rows 4 (l >> 4) .. + 3 of each 16-row tile; a relation's 32 head features are two such tiles; the sum over them is
+// eight products per lane plus two exchanges between the four lane groups; lane group q then stores column tile q, so a
+// (32-row group, 64 words) share leaves as ONE 256-byte store.
+__device__ __forceinline__ void at_heads_epilogue16(f32x4v (&acc)[8][4], const LinearArgs &a, int m0, int n0, int wm, int wn,
+                                                    int lane) {
+    asm volatile("" : "+v"(lane));  // (opaque: nothing lane-dependent of the epilogue is hoisted out of the tile loop and kept -- or
+                                    // spilled -- across the main loop)
+    const int q = lane >> 4, c16 = lane & 15;
+    int word[4];
+    float cs[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        word[j] = n0 + wn * 64 + 16 * j + c16;
+        cs[j] = word[j] < a.N ? a.col_scale[word[j]] : 0.f;
+    }
+    const int grp0 = __builtin_amdgcn_readfirstlane((m0 >> 5) + wm * 4);
+    float4 x[4][2];
+    int cur_blk = -1;
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi) {
+        const int grp = grp0 + gi, tile_row = grp << 5;
+        const int blk = grp / a.nrel;
+        const bool tv = tile_row < a.M;
+        if (blk != cur_blk) {  // wave-uniform: the wave's four relations nearly always share one block of 32 head features
+            cur_blk = blk;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const int d2 = blk * 32 + 16 * hf + 4 * q;
+                const long xo = (long)(tv && d2 < a.kpx ? d2 >> 2 : 0) * a.ldx2 * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    x[j][hf] = *reinterpret_cast<const float4 *>(a.x2 + (word[j] < a.N ? word[j] : 0) * 4L + xo);
+            }
+        }
+        float4 rs[2];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const bool valid = tv && blk * 32 + 16 * hf + 4 * q < a.kpx;
+            rs[hf] = valid ? *reinterpret_cast<const float4 *>(a.row_scale + tile_row + 16 * hf + 4 * q)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        float sums[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float sum = 0.f;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {  // ascending feature index: the order of the sum is part of the result
+                sum += acc[2 * gi + hf][j][0] * rs[hf].x * x[j][hf].x;
+                sum += acc[2 * gi + hf][j][1] * rs[hf].y * x[j][hf].y;
+                sum += acc[2 * gi + hf][j][2] * rs[hf].z * x[j][hf].z;
+                sum += acc[2 * gi + hf][j][3] * rs[hf].w * x[j][hf].w;
+            }
+            sum *= cs[j];
+            sum += __shfl_xor(sum, 16);
+            sum += __shfl_xor(sum, 32);
+            sums[j] = sum;
+        }
+        const float mine = q == 0 ? sums[0] : (q == 1 ? sums[1] : (q == 2 ? sums[2] : sums[3]));
+        const int wq = n0 + wn * 64 + lane;  // = the word of column tile q at this lane's column
+        if (wq < a.N && tv) a.P[(long)grp * a.N + wq] = mine;
+    }
+}
+
+__global__ __launch_bounds__(512, 1) void linear_f16x3_wide16_heads_kernel(LinearArgs a) {
+    constexpr int BM = 256, ROWS = 512, PBUF = ROWS * 128;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    __shared__ int s_next;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int npair = a.K >> 5;
+    const int xg = blockIdx.x & 7;
+    const int ntiles = a.num_m * a.num_n, q8 = ntiles >> 3, r8 = ntiles & 7;
+    const int chunk0 = xg < r8 ? xg * (q8 + 1) : r8 * (q8 + 1) + (xg - r8) * q8;
+    const int chunkn = q8 + (xg < r8 ? 1 : 0);
+    if (tid == 0) s_next = atomicAdd(a.tile_ctr + xg, 1);
+    __syncthreads();
+    const int first = __builtin_amdgcn_readfirstlane(s_next);
+    if (first >= chunkn) return;
+    int m0, n0;
+    wide_tile_origin(a, chunk0 + first, m0, n0);
+
+    // DMA: wave-load u = 8q + wave fills rows 8u .. 8u+7; lane i writes slot i & 7 of row i >> 3, fetching the global chunk whose
+    // slot that is: global chunk (2g + piece) lives at slot (piece + {0,6,2,4}[g]) ^ ((R >> 1) & 7)
+    // The lane's eight loads of a pair: rows 64 q + (8 wave + lr) of the tile's 256 A rows (q < 4) and B rows, chunk `chunk`
+    // of the pair's 128 bytes.  Address = uniform base (image + tile origin + pair, SGPRs) + a 32-bit lane offset that is
+    // computed per issue from ONE register per operand (the offset inside a 64-row group) by an add and a min: the min
+    // against the lane's last valid offset in the tile clamps rows beyond the matrix to its last row, as the 32 x 32 kernels'
+    // eight precomputed pointers do -- sixteen registers there, four here.
+    const unsigned char *const baseX = reinterpret_cast<const unsigned char *>(a.X);
+    const unsigned char *const baseW = reinterpret_cast<const unsigned char *>(a.W);
+    unsigned offA, offB, maxA = 0, maxB = 0;
+    const unsigned char *tileX = baseX, *tileW = baseW;
+    auto lane_chunk16 = [&]() {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));  // (recomputed where needed rather than kept in a register across the main loop)
+        const int cphys = (ln & 7) ^ (((wave & 1) << 2) + (ln >> 4));  // (slot) ^ ((R >> 1) & 7), R = 64q + 8 wave + (ln >> 3)
+        return (unsigned)((0x32765410 >> (4 * cphys)) & 7) * 16u;      // physical chunk number -> global chunk 2g + piece
+    };
+    {
+        const unsigned r8 = 8 * wave + (lane >> 3), c16 = lane_chunk16();
+        offA = r8 * (unsigned)a.ldx + c16;
+        offB = r8 * (unsigned)a.ldw + c16;
+    }
+    auto set_src = [&](int mm, int nn) {
+        const unsigned c16 = lane_chunk16();
+        tileX = baseX + (long)mm * a.ldx;
+        tileW = baseW + (long)nn * a.ldw;
+        maxA = (unsigned)(a.M - 1 - mm) * (unsigned)a.ldx + c16;  // (the tile's origin is inside the matrix)
+        maxB = (unsigned)(a.N - 1 - nn) * (unsigned)a.ldw + c16;
+    };
+    const unsigned strideA = 64u * (unsigned)a.ldx, strideB = 64u * (unsigned)a.ldw;
+    auto dma = [&](int q, const unsigned char *sx, const unsigned char *sw, unsigned lds_addr) {  // sx / sw: tile base + pair offset
+        if (q < 4) {
+            const unsigned v = offA + (unsigned)q * strideA;
+            lds_dma16_s(sx, v < maxA ? v : maxA, lds_addr);
+        } else {
+            const unsigned v = offB + (unsigned)(q - 4) * strideB;
+            lds_dma16_s(sw, v < maxB ? v : maxB, lds_addr);
+        }
+    };
+    set_src(m0, n0);
+    const unsigned lds0 = (unsigned)(uintptr_t)lds + (unsigned)__builtin_amdgcn_readfirstlane(wave) * 1024u;
+
+    const int r16 = lane & 15, g = lane >> 4;
+    const int c0 = (0x4260 >> (4 * g)) & 7;  // physical chunk number of (g, h); (g, l) = + 1
+    const int sw = r16 >> 1;
+    const int off_h = (c0 ^ sw) << 4, off_l = ((c0 + 1) ^ sw) << 4;
+    const int a_ofs = (wm * 128 + r16) * 128;
+    const int b_ofs = (BM + wn * 64 + r16) * 128;
+
+    f32x4v acc[8][4];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+    };
+    zero_acc();
+    // Row fragments in TWO sets of two 16-row tiles (the wave's eight row tiles = four groups G0..G3; G0 and G2 use set 0,
+    // G1 and G3 set 1): a set is re-read as soon as its group's 24 MFMAs have been issued, and the other group's 24 MFMAs
+    // (384+ cycles of the matrix pipe) cover the read.  64 fragment registers instead of 96.
+    u32x4 ah[2][2], al[2][2], bh[4], bl[4];
+    auto pin = [&]() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(acc[i][j]));
+    };
+    auto read_g = [&](const unsigned char *buf, int G, int S) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            al[S][t] = *reinterpret_cast<const u32x4 *>(buf + a_ofs + (2 * G + t) * 2048 + off_l);
+            ah[S][t] = *reinterpret_cast<const u32x4 *>(buf + a_ofs + (2 * G + t) * 2048 + off_h);
+        }
+    };
+    auto read_bl = [&](const unsigned char *buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bl[j] = *reinterpret_cast<const u32x4 *>(buf + b_ofs + j * 2048 + off_l);
+    };
+    auto read_bh = [&](const unsigned char *buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bh[j] = *reinterpret_cast<const u32x4 *>(buf + b_ofs + j * 2048 + off_h);
+    };
+#define PHONLP_W16_ROUND(G, S, AA, BB)                 \
+    _Pragma("unroll") for (int t = 0; t < 2; ++t)      \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j)      \
+        acc[2 * (G) + t][j] = PHONLP_F16_MFMA16(AA[S][t], BB[j], acc[2 * (G) + t][j]);
+#define PHONLP_W16_GROUP(G, S)        \
+    PHONLP_W16_ROUND(G, S, ah, bl)    \
+    PHONLP_W16_ROUND(G, S, al, bh)    \
+    PHONLP_W16_ROUND(G, S, ah, bh)
+    // One pair out of buffer pb, the same code for every pair of every tile (no branch in it: specialised tail bodies made
+    // hipcc move the accumulators between them and spill; branches around the LDS reads made it read into temporaries, wait,
+    // and copy).  The eight loads at byte offset `so` of the rows set by set_src() go into this pair's buffer between the last
+    // sixteen MFMAs: the pair after next of the tile, or the first two pairs of the NEXT tile during a tile's last two pairs (a
+    // workgroup's last tile loads its own first pairs again: two wasted pair loads per workgroup).
+    // Schedule: read bh, G1 | G0 | read G2 | G1 | read G3 | G2 | G3: ah.bl | wait for the next pair + barrier | read the next
+    // pair's G0 and bl | G3: al.bh, ah.bh with the LDS-DMA issues between the MFMAs.
+    auto body = [&](int pb, long so) {
+        const unsigned char *buf = lds + pb * PBUF;
+        const unsigned char *sx = tileX + so, *sw = tileW + so;
+        read_bh(buf);
+        read_g(buf, 1, 1);
+        pin();
+        PHONLP_W16_GROUP(0, 0)
+        pin();
+        read_g(buf, 2, 0);
+        pin();
+        PHONLP_W16_GROUP(1, 1)
+        pin();
+        read_g(buf, 3, 1);
+        pin();
+        PHONLP_W16_GROUP(2, 0)
+        pin();
+        PHONLP_W16_ROUND(3, 1, ah, bl)
+        pin();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next pair (issued 80+ MFMAs ago) has landed
+        lds_barrier();  // ... everyone's; and everyone has read this pair's fragments: buffer pb is free
+        read_g(lds + (pb ^ 1) * PBUF, 0, 0);
+        read_bl(lds + (pb ^ 1) * PBUF);
+        pin();
+        const unsigned ld = lds0 + (unsigned)(pb * PBUF);
+#define PHONLP_W16_TWO_DMA(AA, T, J, Q)                                                  \
+    acc[6 + T][J] = PHONLP_F16_MFMA16(AA[1][T], bh[J], acc[6 + T][J]);                   \
+    acc[6 + T][J + 1] = PHONLP_F16_MFMA16(AA[1][T], bh[J + 1], acc[6 + T][J + 1]);       \
+    asm volatile("" : "+v"(acc[6 + T][J]), "+v"(acc[6 + T][J + 1]));                     \
+    dma(Q, sx, sw, ld + Q * 8192);
+        PHONLP_W16_TWO_DMA(al, 0, 0, 0)
+        PHONLP_W16_TWO_DMA(al, 0, 2, 1)
+        PHONLP_W16_TWO_DMA(al, 1, 0, 2)
+        PHONLP_W16_TWO_DMA(al, 1, 2, 3)
+        PHONLP_W16_TWO_DMA(ah, 0, 0, 4)
+        PHONLP_W16_TWO_DMA(ah, 0, 2, 5)
+        PHONLP_W16_TWO_DMA(ah, 1, 0, 6)
+        PHONLP_W16_TWO_DMA(ah, 1, 2, 7)
+#undef PHONLP_W16_TWO_DMA
+    };
+    // first tile: pairs 0 and 1
+#pragma unroll
+    for (int q = 0; q < 8; ++q) dma(q, tileX, tileW, lds0 + (unsigned)(q * 8192));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+    read_g(lds, 0, 0);
+    read_bl(lds);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) dma(q, tileX + 128, tileW + 128, lds0 + (unsigned)(PBUF + q * 8192));
+    int pb = 0;
+    for (;;) {
+        int drawn = 0;  // the next tile's number: drawn now, needed npair - 3 pairs from here
+        if (tid == 0) drawn = atomicAdd(a.tile_ctr + xg, 1);
+        bool has_next = false;
+        int m1 = m0, n1 = n0;
+#pragma unroll 1
+        for (int p = 0; p < npair; ++p) {
+            if (p == npair - 3 && tid == 0) s_next = drawn;  // published by this pair's barrier
+            if (p == npair - 2) {  // from here on the loads are the next tile's first two pairs
+                const int nxt = __builtin_amdgcn_readfirstlane(s_next);
+                has_next = nxt < chunkn;
+                if (has_next) {
+                    wide_tile_origin(a, chunk0 + nxt, m1, n1);
+                    set_src(m1, n1);
+                }
+            }
+            body(pb, (long)(p + 2 < npair ? p + 2 : p + 2 - npair) * 128);
+            pb ^= 1;
+        }
+        // (the last pair's barrier stood behind the arrival of the next tile's pair 0, whose first fragments are in registers)
+        at_heads_epilogue16(acc, a, m0, n0, wm, wn, lane);
+        if (!has_next) break;
+        zero_acc();
+        m0 = m1;
+        n0 = n1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last tile's surplus loads land before the workgroup's LDS is released
+#undef PHONLP_W16_GROUP
+#undef PHONLP_W16_ROUND
+}
+
 int launch_linear_f16x3(const char *tag, const void *Xp, long pitch_x, const float *x_inv, const void *Wp, long pitch_w,
                         const float *w_inv, const float *bias, float *Y, long ldy, int M, int N, int K16, int relu,
                         const int32_t *sentlens, int L, hipStream_t stream, const float *pad_bias, int rows4 = 0,
@@ -1288,9 +1580,10 @@ int launch_linear_f16x3(const char *tag, const void *Xp, long pitch_x, const flo
         if (persist_once.pending(&pdev)) {
             int cus = 0;
             const void *pf[] = {(const void *)linear_f16x3_wide_persist_kernel<0>, (const void *)linear_f16x3_wide_persist_kernel<1>,
-                                (const void *)linear_f16x3_wide_persist_kernel<2>};
-            for (int k = 0; k < 3; ++k)
-                if (hipFuncSetAttribute(pf[k], hipFuncAttributeMaxDynamicSharedMemorySize, k ? LDS_WIDE_T : LDS_WIDE) != hipSuccess)
+                                (const void *)linear_f16x3_wide_persist_kernel<2>, (const void *)linear_f16x3_wide16_heads_kernel};
+            for (int k = 0; k < 4; ++k)
+                if (hipFuncSetAttribute(pf[k], hipFuncAttributeMaxDynamicSharedMemorySize, (k == 1 || k == 2) ? LDS_WIDE_T : LDS_WIDE) !=
+                    hipSuccess)
                     return -1;
             if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, pdev) != hipSuccess || cus < 8) return -1;
             n_cu[pdev & 63] = cus;
@@ -1343,7 +1636,9 @@ int launch_linear_f16x3(const char *tag, const void *Xp, long pitch_x, const flo
             if (cap < 0) return fail(PHONLP_ERR_LAUNCH, "linear_split: cannot set up the persistent stage A");
             a.tile_ctr = at_heads->tile_ctr;
             ProfScope psh(tag, stream);
-            hipLaunchKernelGGL(linear_f16x3_wide_persist_kernel<0>, dim3(want < cap ? want : cap), dim3(512), LDS_WIDE, stream, a);
+            static const int w16 = getenv("PHONLP_X3_W16") ? atoi(getenv("PHONLP_X3_W16")) : 1;  // TEMP A/B
+            if (w16) hipLaunchKernelGGL(linear_f16x3_wide16_heads_kernel, dim3(want < cap ? want : cap), dim3(512), LDS_WIDE, stream, a);
+            else hipLaunchKernelGGL(linear_f16x3_wide_persist_kernel<0>, dim3(want < cap ? want : cap), dim3(512), LDS_WIDE, stream, a);
             return check_launch("linear_f16x3_wide_persist_kernel");
         }
         ProfScope psw(tag, stream);
