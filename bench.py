@@ -562,11 +562,11 @@ def main():
                     1: "bf16x6: fp32 operands split exactly into 3 bf16 pieces, 6 v_mfma_f32_32x32x16_bf16 products, "
                        "f32 accumulate (fp32-grade error, tests/test_gpu_parity.py::test_engines_against_fp64)",
                     2: "f16x3: fp32 operands scaled per row by a power of two and split into 2 f16 pieces once per "
-                       "element (split images), 3 v_mfma_f32_32x32x16_f16 products, f32 accumulate (fp32-grade error, "
+                       "element (split images), 3 f16 MFMA products (32x32x16; the dominant kernel 16x16x32), f32 accumulate (fp32-grade error, "
                        "tests/test_gpu_parity.py::test_engines_against_fp64); small layers and stage B run bf16x6"}
         short = {0: "f32 MFMA", 1: "bf16x6", 2: "f16x3"}
         kern = {0: "linear_kernel<128,128,2,2,1,0>", 1: "linear_split256_kernel<1>",
-                2: ("linear_f16x3_wide_persist_kernel<0> (persistent 256x256 tiles) with the labels-at-heads epilogue (T never stored)" if fused else
+                2: ("linear_f16x3_wide16_heads_kernel (persistent 256x256 tiles, v_mfma_f32_16x16x32_f16) with the labels-at-heads epilogue (T never stored)" if fused else
                     "linear_f16x3_dma_kernel<1, false, true>")}
         peak_note = {0: "dense fp32 MFMA peak",
                      1: "algorithmic (fp32-equivalent) TFLOP/s; engine 1 peak = 2500 bf16 dense / 6 products",

@@ -219,14 +219,17 @@ __device__ __forceinline__ void at_heads_epilogue(f32x16 (&acc)[TM][TN], const L
 
 // Transposed dense-layer epilogue (persistent wide kernel, EPI 1 / 2): the product is taken with the WEIGHT image as the
 // row operand and the words' image as the column operand, as for the labels-at-heads above, so an accumulator lane holds
-// ONE word and four groups of four CONSECUTIVE output features: bias / ReLU / padding mask are applied in registers.  A
-// 32 x 32 accumulator tile is then 128 contiguous bytes of each of 32 words' rows, both as fp32 (IMAGE = false) and as f16
-// pieces of the split image (IMAGE = true; LinearArgs::img, scale from the bound as in linear_epilogue) -- but spread over
-// a word's two lanes and four register groups.  Stored from there (8 / 16 bytes per lane, 32 different lines per
-// instruction) the stores cost a third of the layer: the CU's path to L2 takes a request per LINE touched, whatever it
-// carries (halving the bytes: -3 %; an L2-resident target: still 60 % of the cost).  So the tile goes through the wave's
-// own 4 KB of LDS (the 32 KB the two pair buffers leave free; chunk c of word r at slot c ^ ((r >> 1) & 7): two-way on the
-// writes, conflict-free on the reads) and leaves as FULL lines, eight lanes a word: an eighth of the requests.
+// ONE word and four groups of four CONSECUTIVE output features.  A 32 x 32 accumulator tile is 128 contiguous bytes of
+// each of 32 words' rows, both as fp32 (IMAGE = false) and as f16 pieces of the split image (IMAGE = true;
+// LinearArgs::img, scale from the bound as in linear_epilogue) -- but spread over a word's two lanes and four register
+// groups.  Stored from there (8 / 16 bytes per lane, 32 different lines per instruction) the stores cost a third of the
+// layer: the CU's path to L2 takes a request per LINE touched, whatever it carries (halving the bytes: -3 %; an
+// L2-resident target: still 60 % of the cost).  So the tile goes through the wave's own 4 KB of LDS (the 32 KB the two
+// pair buffers leave free; fp32, scaled by the word's inverse scale; chunk c of word r at slot c ^ ((r >> 1) & 7):
+// conflict-free both ways) and is read back EIGHT LANES A WORD, lane = (word, four consecutive features): in that layout
+// the per-feature terms (inverse scale, bias, ReLU, padding value) depend on lane & 7 alone -- a dozen ds_bpermute per
+// tile row instead of a dozen per register group --, the f16 pieces of two neighbouring lanes are exchanged by DPP into
+// whole 16-byte chunks (h[8] | l[8]), and every store instruction writes eight FULL 128-byte lines.
 // a.M = output features (a.row_scale, a.bias, a.pad_bias per feature; a multiple of 4 -- 8 for the image --, the three
 // arrays 16-byte aligned: the launcher checks), a.N = words (a.col_scale per word, a.sentlens / a.L their padding mask),
 // Y[word * ldy + feature].
@@ -238,36 +241,49 @@ __device__ __forceinline__ void transposed_epilogue(f32x16 (&acc)[TM][TN], const
     // The patch is addressed as an OFFSET into the kernel's LDS array: a pointer through the asm would lose its address
     // space and turn the ds_ accesses into flat ones.)
     asm volatile("" : "+v"(lane), "+v"(patch_ofs));
+    static_assert(TM * 32 == 128 && TN == 2, "two registers of 64 features, two column tiles per wave");
     unsigned char *patch = lds_base + patch_ofs;
     const int half = lane >> 5, l32 = lane & 31;
-    int word[TN];
-    float cs[TN], isc[TN];
-    bool live[TN];
+    const int rw = lane >> 3, rk = lane & 7;  // read side: word 8q + rw of a column tile, features 4 rk .. 4 rk + 3 of a tile row
+    // write side: the word's inverse scale
+    float cs[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        word[j] = n0 + (wn * TN + j) * 32 + l32;
-        const bool wv = word[j] < a.N;
-        cs[j] = wv ? a.col_scale[word[j]] : 0.f;
-        live[j] = wv && (!a.sentlens || (word[j] % a.L) < a.sentlens[word[j] / a.L]);
-        isc[j] = 1.f;
-        if constexpr (IMAGE) {
-            float inv;
-            image_scale_of_bound(a.img_c * cs[j] * 32768.f + a.img_b, isc[j], inv);
-            if (wv && m0 == 0 && wm == 0 && half == 0) a.img_inv[word[j]] = inv;
-        }
+        const int w = n0 + (wn * TN + j) * 32 + l32;
+        cs[j] = w < a.N ? a.col_scale[w] : 0.f;
     }
+    // read side: the lane's eight words of the wave's two column tiles
+    unsigned wofs[TN][4];   // byte offset of the word's output row
+    float isc[TN][4];       // image: the word's scale
+    unsigned okmask = 0, livemask = 0;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int wd = n0 + (wn * TN + j) * 32 + 8 * q + rw;
+            const bool ok = wd < a.N;
+            const int wc = ok ? wd : 0;
+            const bool lv = ok && (!a.sentlens || (wc % a.L) < a.sentlens[wc / a.L]);
+            okmask |= (ok ? 1u : 0u) << (4 * j + q);
+            livemask |= (lv ? 1u : 0u) << (4 * j + q);
+            isc[j][q] = 1.f;
+            if constexpr (IMAGE) {
+                float inv;
+                image_scale_of_bound(a.img_c * (ok ? a.col_scale[wc] : 0.f) * 32768.f + a.img_b, isc[j][q], inv);
+                if (ok && m0 == 0 && wm == 0 && rk == 0) a.img_inv[wd] = inv;
+                wofs[j][q] = (unsigned)wc * (unsigned)a.img_pitch;
+            } else {
+                wofs[j][q] = (unsigned)wc * (unsigned)a.ldy * 4u;
+            }
+        }
     const int relu_n = a.relu > 0 ? INT_MAX : -a.relu;
     const bool vec_ok = IMAGE || (((a.ldy & 3) == 0) && (((uintptr_t)a.Y & 15) == 0));
     unsigned char *wr_row = patch + l32 * 128;
     const int wsw = (l32 >> 1) & 7;
-    // read side: lane = (word 8q + (lane >> 3) of the tile, 16-byte piece lane & 7 of its 128 bytes)
-    const int rw = lane >> 3, rk = lane & 7;
     // Per-feature scales, biases and padding values of the wave's TM * 32 features: ONE load per lane and array at the top
     // (lane t holds feature t, a second register features 64 ..), handed to the lanes that need them by ds_bpermute.  Loads
     // inside the loop would sit behind this tile's stores in the in-order vector-memory queue: waiting for one would mean
-    // waiting for those stores' acknowledgements (four stalls of a microsecond per tile); hoisted as float4 per group they
-    // spill.
-    static_assert(TM * 32 == 128, "two registers of 64 features");
+    // waiting for those stores' acknowledgements.
     const int fw = m0 + wm * (TM * 32);
     const int fa = fw + lane < a.M ? fw + lane : a.M - 1, fb = fw + 64 + lane < a.M ? fw + 64 + lane : a.M - 1;
     float rsA = a.row_scale[fa], rsB = a.row_scale[fb];
@@ -277,80 +293,88 @@ __device__ __forceinline__ void transposed_epilogue(f32x16 (&acc)[TM][TN], const
     // (waited for HERE, and handed on as the asm's results: the compiler's own wait for a loaded register would be placed at its
     // first use inside the loop as vmcnt(n) counted over ALL vector-memory operations, this tile's stores included)
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(rsA), "+v"(rsB), "+v"(bA), "+v"(bB), "+v"(pA), "+v"(pB));
-    static_assert(TN == 2, "two column tiles per wave");
-    asm volatile("" : "+v"(cs[0]), "+v"(cs[1]));
+    asm volatile("" : "+v"(cs[0]), "+v"(cs[1]), "+v"(okmask), "+v"(livemask));
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(wofs[j][q]), "+v"(isc[j][q]));
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        const int f0 = __builtin_amdgcn_readfirstlane(m0 + (wm * TM + i) * 32);  // the tile's first feature
+        const int f0 = __builtin_amdgcn_readfirstlane(m0 + (wm * TM + i) * 32);  // the tile row's first feature
         if (f0 >= a.M) continue;
+        // the read-side lane's four features f0 + 4 rk + e
+        const int t = 32 * (i & 1) + 4 * rk;
+        const float rv = i < 2 ? rsA : rsB, bb = i < 2 ? bA : bB, pp = i < 2 ? pA : pB;
+        const float4 rs = make_float4(__shfl(rv, t), __shfl(rv, t + 1), __shfl(rv, t + 2), __shfl(rv, t + 3));
+        const float4 bv = make_float4(__shfl(bb, t), __shfl(bb, t + 1), __shfl(bb, t + 2), __shfl(bb, t + 3));
+        const int f = f0 + 4 * rk;
+        float4 lo;  // ReLU as a lower clamp: 0 where it applies, -inf elsewhere
+        lo.x = (a.relu && f < relu_n) ? 0.f : -INFINITY;
+        lo.y = (a.relu && f + 1 < relu_n) ? 0.f : -INFINITY;
+        lo.z = (a.relu && f + 2 < relu_n) ? 0.f : -INFINITY;
+        lo.w = (a.relu && f + 3 < relu_n) ? 0.f : -INFINITY;
+        float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);  // value of a padded word: act(pad_bias), or zeros
+        if (a.pad_bias) {
+            pv = make_float4(fmaxf(__shfl(pp, t), lo.x), fmaxf(__shfl(pp, t + 1), lo.y), fmaxf(__shfl(pp, t + 2), lo.z),
+                             fmaxf(__shfl(pp, t + 3), lo.w));
+        }
+        const bool piece_ok = f < a.M;  // (a.M % 4 == 0; the image's a.M % 8 == 0 makes both lanes of a chunk agree)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int f = f0 + 8 * g + 4 * half;
-                const int t = 32 * (i & 1) + 8 * g + 4 * half;  // source lane of the group's first feature
-                const float rv = i < 2 ? rsA : rsB, bb = i < 2 ? bA : bB;
-                const float4 rs1 = make_float4(__shfl(rv, t), __shfl(rv, t + 1), __shfl(rv, t + 2), __shfl(rv, t + 3));
-                const float4 bv1 = make_float4(__shfl(bb, t), __shfl(bb, t + 1), __shfl(bb, t + 2), __shfl(bb, t + 3));
-                float4 lo;  // ReLU as a lower clamp: 0 where it applies, -inf elsewhere
-                lo.x = (a.relu && f < relu_n) ? 0.f : -INFINITY;
-                lo.y = (a.relu && f + 1 < relu_n) ? 0.f : -INFINITY;
-                lo.z = (a.relu && f + 2 < relu_n) ? 0.f : -INFINITY;
-                lo.w = (a.relu && f + 3 < relu_n) ? 0.f : -INFINITY;
-                float4 v;  // (acc * 2^-ka) * 2^-kb: exact, in the order of linear_epilogue
-                v.x = fmaxf(acc[i][j][4 * g + 0] * cs[j] * rs1.x + bv1.x, lo.x);
-                v.y = fmaxf(acc[i][j][4 * g + 1] * cs[j] * rs1.y + bv1.y, lo.y);
-                v.z = fmaxf(acc[i][j][4 * g + 2] * cs[j] * rs1.z + bv1.z, lo.z);
-                v.w = fmaxf(acc[i][j][4 * g + 3] * cs[j] * rs1.w + bv1.w, lo.w);
-                if (a.sentlens) {  // (uniform) a padded word: act(pad_bias), or zeros
-                    const float pp = i < 2 ? pA : pB;
-                    const float4 pb = make_float4(__shfl(pp, t), __shfl(pp, t + 1), __shfl(pp, t + 2), __shfl(pp, t + 3));
-                    if (!live[j]) {
-                        v = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (a.pad_bias) { v.x = fmaxf(pb.x, lo.x); v.y = fmaxf(pb.y, lo.y); v.z = fmaxf(pb.z, lo.z); v.w = fmaxf(pb.w, lo.w); }
-                    }
-                } else if (!live[j]) {
-                    v = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-                if constexpr (IMAGE) {  // chunk 2g = h[8], 2g + 1 = l[8] of features 8g .. 8g + 7; this lane's four at byte 8 half
-                    const float s4[4] = {v.x * isc[j], v.y * isc[j], v.z * isc[j], v.w * isc[j]};  // exact (powers of two)
+            for (int g = 0; g < 4; ++g) {  // chunk 2g + half = features 8g + 4 half .. + 3 of the word; (acc * 2^-ka): exact
+                const float4 v = make_float4(acc[i][j][4 * g + 0] * cs[j], acc[i][j][4 * g + 1] * cs[j], acc[i][j][4 * g + 2] * cs[j],
+                                             acc[i][j][4 * g + 3] * cs[j]);
+                *reinterpret_cast<float4 *>(wr_row + (((2 * g + half) ^ wsw) << 4)) = v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            float4 d[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = 8 * q + rw;
+                d[q] = *reinterpret_cast<const float4 *>(patch + r * 128 + ((rk ^ ((r >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 v;  // (. * 2^-kb) + bias, activation: as linear_epilogue
+                v.x = fmaxf(d[q].x * rs.x + bv.x, lo.x);
+                v.y = fmaxf(d[q].y * rs.y + bv.y, lo.y);
+                v.z = fmaxf(d[q].z * rs.z + bv.z, lo.z);
+                v.w = fmaxf(d[q].w * rs.w + bv.w, lo.w);
+                if (!((livemask >> (4 * j + q)) & 1u)) v = pv;
+                const bool st = ((okmask >> (4 * j + q)) & 1u) && piece_ok;
+                if constexpr (IMAGE) {
+                    const float s4[4] = {v.x * isc[j][q], v.y * isc[j][q], v.z * isc[j][q], v.w * isc[j][q]};  // exact (powers of two)
                     img_f16x4 h, l;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         h[e] = (_Float16)s4[e];
                         l[e] = (_Float16)(s4[e] - (float)h[e]);
                     }
-                    *reinterpret_cast<img_f16x4 *>(wr_row + (((2 * g) ^ wsw) << 4) + 8 * half) = h;
-                    *reinterpret_cast<img_f16x4 *>(wr_row + (((2 * g + 1) ^ wsw) << 4) + 8 * half) = l;
-                } else {  // chunk 2g + half = features 8g + 4 half .. + 3
-                    *reinterpret_cast<float4 *>(wr_row + (((2 * g + half) ^ wsw) << 4)) = v;
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            // piece rk of a word's 128 bytes: image -- features 8 (rk >> 1) .. + 7 (h or l); fp32 -- features 4 rk .. + 3
-            const bool piece_ok = f0 + (IMAGE ? 8 * (rk >> 1) : 4 * rk) < a.M;
-            u32x4 d[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int r = 8 * q + rw;
-                d[q] = *reinterpret_cast<const u32x4 *>(patch + r * 128 + ((rk ^ ((r >> 1) & 7)) << 4));
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int wd = n0 + (wn * TN + j) * 32 + 8 * q + rw;
-                if (wd >= a.N || !piece_ok) continue;
+                    // features 8m .. 8m+7 are the lane pair (rk = 2m, 2m+1): the even lane stores the chunk h[8], the odd one l[8]
+                    const uint2 hh2 = __builtin_bit_cast(uint2, h), ll2 = __builtin_bit_cast(uint2, l);
+                    const uint2 give = (rk & 1) ? hh2 : ll2;
+                    uint2 got;
+                    got.x = (unsigned)__builtin_amdgcn_update_dpp(0, (int)give.x, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
+                    got.y = (unsigned)__builtin_amdgcn_update_dpp(0, (int)give.y, 0xB1, 0xF, 0xF, false);
+                    u32x4 out;
+                    if (rk & 1) { out[0] = got.x; out[1] = got.y; out[2] = ll2.x; out[3] = ll2.y; }
+                    else { out[0] = hh2.x; out[1] = hh2.y; out[2] = got.x; out[3] = got.y; }
 #ifdef PHONLP_ABLATION
-                if (a.dbg == 1 && d[q][0] != 0x12345u) continue;
+                    if (a.dbg == 1 && out[0] != 0x12345u) continue;
 #endif
-                if constexpr (IMAGE) {
-                    *reinterpret_cast<u32x4 *>(a.img + (long)wd * a.img_pitch + (long)f0 * 4 + rk * 16) = d[q];
+                    if (st) *reinterpret_cast<u32x4 *>(a.img + wofs[j][q] + (unsigned)f0 * 4u + rk * 16) = out;
                 } else {
-                    float *y = a.Y + (long)wd * a.ldy + f0 + 4 * rk;
-                    if (vec_ok) {
-                        *reinterpret_cast<u32x4 *>(y) = d[q];
-                    } else {
-                        y[0] = __uint_as_float(d[q][0]); y[1] = __uint_as_float(d[q][1]);
-                        y[2] = __uint_as_float(d[q][2]); y[3] = __uint_as_float(d[q][3]);
+#ifdef PHONLP_ABLATION
+                    if (a.dbg == 1 && v.x != 1234.5f) continue;
+#endif
+                    float *y = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(a.Y) + wofs[j][q]) + f;
+                    if (st) {
+                        if (vec_ok) {
+                            *reinterpret_cast<float4 *>(y) = v;
+                        } else {
+                            y[0] = v.x; y[1] = v.y; y[2] = v.z; y[3] = v.w;
+                        }
                     }
                 }
             }
@@ -1579,11 +1603,10 @@ int launch_linear_f16x3(const char *tag, const void *Xp, long pitch_x, const flo
         int pdev;
         if (persist_once.pending(&pdev)) {
             int cus = 0;
-            const void *pf[] = {(const void *)linear_f16x3_wide_persist_kernel<0>, (const void *)linear_f16x3_wide_persist_kernel<1>,
-                                (const void *)linear_f16x3_wide_persist_kernel<2>, (const void *)linear_f16x3_wide16_heads_kernel};
-            for (int k = 0; k < 4; ++k)
-                if (hipFuncSetAttribute(pf[k], hipFuncAttributeMaxDynamicSharedMemorySize, (k == 1 || k == 2) ? LDS_WIDE_T : LDS_WIDE) !=
-                    hipSuccess)
+            const void *pf[] = {(const void *)linear_f16x3_wide16_heads_kernel, (const void *)linear_f16x3_wide_persist_kernel<1>,
+                                (const void *)linear_f16x3_wide_persist_kernel<2>};
+            for (int k = 0; k < 3; ++k)
+                if (hipFuncSetAttribute(pf[k], hipFuncAttributeMaxDynamicSharedMemorySize, k ? LDS_WIDE_T : LDS_WIDE) != hipSuccess)
                     return -1;
             if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, pdev) != hipSuccess || cus < 8) return -1;
             n_cu[pdev & 63] = cus;
@@ -1636,10 +1659,8 @@ int launch_linear_f16x3(const char *tag, const void *Xp, long pitch_x, const flo
             if (cap < 0) return fail(PHONLP_ERR_LAUNCH, "linear_split: cannot set up the persistent stage A");
             a.tile_ctr = at_heads->tile_ctr;
             ProfScope psh(tag, stream);
-            static const int w16 = getenv("PHONLP_X3_W16") ? atoi(getenv("PHONLP_X3_W16")) : 1;  // TEMP A/B
-            if (w16) hipLaunchKernelGGL(linear_f16x3_wide16_heads_kernel, dim3(want < cap ? want : cap), dim3(512), LDS_WIDE, stream, a);
-            else hipLaunchKernelGGL(linear_f16x3_wide_persist_kernel<0>, dim3(want < cap ? want : cap), dim3(512), LDS_WIDE, stream, a);
-            return check_launch("linear_f16x3_wide_persist_kernel");
+            hipLaunchKernelGGL(linear_f16x3_wide16_heads_kernel, dim3(want < cap ? want : cap), dim3(512), LDS_WIDE, stream, a);
+            return check_launch("linear_f16x3_wide16_heads_kernel");
         }
         ProfScope psw(tag, stream);
         const dim3 gw(a.num_m * a.num_n);

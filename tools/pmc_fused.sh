@@ -18,7 +18,7 @@ for p in ("p1","p2","p3"):
     f = glob.glob("$OUT/%s/**/*counter_collection.csv" % p, recursive=True)
     acc = collections.defaultdict(list)
     for row in csv.DictReader(open(f[0])):
-        if "linear_f16x3_wide16_heads_kernel" in row["Kernel_Name"] or "linear_f16x3_wide_persist_kernel<0>" in row["Kernel_Name"] or "linear_f16x3_wide_kernel<1>" in row["Kernel_Name"] or "linear_f16x3_dma_kernel<1, false" in row["Kernel_Name"]:
+        if "linear_f16x3_wide16_heads_kernel" in row["Kernel_Name"] or "linear_f16x3_wide_kernel<1>" in row["Kernel_Name"] or "linear_f16x3_dma_kernel<1, false" in row["Kernel_Name"]:
             acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
     for k, v in sorted(acc.items()):
         print(p, k, "n=%d" % len(v), "mean=%.5g" % (sum(v)/len(v)))

@@ -15,7 +15,7 @@ t = json.load(open(tpath))
 bench = json.loads(open(os.path.join(src, "bench_under_rocprof.json")).read().strip().splitlines()[-1])
 fused = "labels-at-heads epilogue" in bench["roofline"]["kernel"]
 for k in summ["per_kernel"]:
-    if "linear_f16x3_wide_persist_kernel<0>" in k["kernel"] or "linear_f16x3_wide_kernel<1>" in k["kernel"] or "linear_f16x3_dma_kernel<1, false" in k["kernel"]:
+    if "linear_f16x3_wide16_heads_kernel" in k["kernel"] or "linear_f16x3_wide_kernel<1>" in k["kernel"] or "linear_f16x3_dma_kernel<1, false" in k["kernel"]:
         key = "linear:label_stage_a@engine2" + ("+fused" if fused else "")
         t[key] = k["hbm_bytes_per_launch_corrected"]
         t[key + "_detail"] = {"FETCH_SIZE_KB": k["FETCH_SIZE_KB_per_launch"], "WRITE_SIZE_KB": k["WRITE_SIZE_KB_per_launch"]}
