@@ -108,18 +108,25 @@ struct ArcSplitLayout {
 
 // LONG = false: sentences of up to 128 words (one block per sentence, one group of head columns: the loops over them fold
 // away, which the register allocation of the headline shape needs); true: up to 512.
-template <int NT, bool LONG>
+// SKIP (short sentences, L <= 96: a variant of its own, so that the headline shape keeps its register allocation): the waves of
+// row tiles and head columns beyond the sentence do not compute.
+template <int NT, bool LONG, bool SKIP = false>
 __global__ __launch_bounds__(512, 1) void arc_f16x3_kernel(ArcSplitArgs a) {
     using Ly = ArcSplitLayout<NT>;
     constexpr int KC = Ly::KC, NTW = Ly::NTW, NLW = Ly::NLW, STAGE_A = Ly::STAGE_A, SLAB_B = Ly::SLAB_B;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int mt = wave & 3, nh = wave >> 2;  // row tile (dependents 32 mt ..), half (phase A: output features; B: head columns)
+    // row tile (dependents 32 mt ..), half (phase A: output features; B: head columns).  Waves 2 mt and 2 mt + 1 share a row tile and
+    // sit on different SIMDs (wave % 4), so a short sentence's live row tiles spread over the SIMDs: the waves of a row tile
+    // beyond the sentence (`dead`) only take part in the loads and barriers, and with up to 64 words every SIMD runs ONE
+    // computing wave instead of two (B = 1, L = 32: 0.14 -> 0.09 ms)
+    const int mt = LONG ? (wave & 3) : (wave >> 1), nh = LONG ? (wave >> 2) : (wave & 1);  // (LONG: the mapping it was tuned with)
     const int r = lane & 31, hh = lane >> 5;
     const int b = blockIdx.x, L = a.L;
     const int i0 = LONG ? 128 * blockIdx.y : 0;  // the block's dependents: i0 .. i0 + 127 (sentences longer than 128 words: several blocks)
     const int len = a.off ? min(max(a.sentlens[b], 0), L) : L;  // dependents scored; heads j < len are real rows
     if (i0 >= len) return;  // packed: nothing but padded dependents here (block-uniform)
+    const bool dead = SKIP && i0 + 32 * mt >= len;  // wave-uniform
     const int NJG = LONG ? (L + 127) >> 7 : 1;   // groups of 128 head columns
     const long rowbase = a.off ? a.off[b] : (long)b * L;
     float *rowfac = reinterpret_cast<float *>(lds + Ly::RING);  // [4][32]
@@ -185,6 +192,13 @@ __global__ __launch_bounds__(512, 1) void arc_f16x3_kernel(ArcSplitArgs a) {
             const unsigned char *wbuf = buf + 8192 + nh * (NTW * 2048);
             const unsigned ld = lds0 + (unsigned)(nxt2 * STAGE_A);
             const long so = (long)(st + 2) * 64;
+            if (dead) {  // no dependents in this wave's row tile: its share of the loads only
+                if constexpr (decltype(issue)::value) {
+#pragma unroll
+                    for (int q = 0; q < NLW; ++q) arc_dma16(srcA[q] + so, ld + q * 8192);
+                }
+                return;
+            }
             const u32x4 xh = *reinterpret_cast<const u32x4 *>(buf + (32 * mt + r) * 64 + off_h);
             const u32x4 xl = *reinterpret_cast<const u32x4 *>(buf + (32 * mt + r) * 64 + off_l);
             u32x4 wh[2][2], wl[2][2];
@@ -316,7 +330,8 @@ __global__ __launch_bounds__(512, 1) void arc_f16x3_kernel(ArcSplitArgs a) {
         for (int k = 0; k < 2; ++k)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc2[k][e] = 0.f;
-        if (nh == 0) convert(0, 0);
+        if (nh == 0 && !dead) convert(0, 0);
+        const bool idle = SKIP && (dead || jbase + 64 * nh >= L);  // no dependents, or none of the wave's head columns: loads and barriers only
 #pragma unroll
         for (int c = 0; c < NT; ++c) {
             {  // slab c landed; the slabs issued behind it (up to DB - 1 of them) may stay in flight
@@ -330,38 +345,43 @@ __global__ __launch_bounds__(512, 1) void arc_f16x3_kernel(ArcSplitArgs a) {
             const unsigned char *slab = lds + (c % NSLAB) * SLAB_B;
             const unsigned char *pt = patch + (c & 1) * 4096;
             const unsigned ld = lds0 + (unsigned)(((c + DB) % NSLAB) * SLAB_B);
-            u32x4 th[2], tl[2];
+            if (!idle) {
+                u32x4 th[2], tl[2];
 #pragma unroll
-            for (int st2 = 0; st2 < 2; ++st2) {
-                th[st2] = *reinterpret_cast<const u32x4 *>(pt + st2 * 2048 + r * 64 + off_h);
-                tl[st2] = *reinterpret_cast<const u32x4 *>(pt + st2 * 2048 + r * 64 + off_l);
-            }
-            // four groups (stage, column tile) of three MFMAs: the next group's fragments are read in front of a group, one
-            // of the two LDS-DMA issues of slab c + 2 follows every other group
-            u32x4 qh[2], ql[2];
-            auto read_q = [&](int gi, int slot) {
-                const int st2 = gi >> 1, jt = 2 * nh + (gi & 1);
-                qh[slot] = *reinterpret_cast<const u32x4 *>(slab + st2 * 8192 + (32 * jt + r) * 64 + off_h);
-                ql[slot] = *reinterpret_cast<const u32x4 *>(slab + st2 * 8192 + (32 * jt + r) * 64 + off_l);
-            };
-            read_q(0, 0);
+                for (int st2 = 0; st2 < 2; ++st2) {
+                    th[st2] = *reinterpret_cast<const u32x4 *>(pt + st2 * 2048 + r * 64 + off_h);
+                    tl[st2] = *reinterpret_cast<const u32x4 *>(pt + st2 * 2048 + r * 64 + off_l);
+                }
+                // four groups (stage, column tile) of three MFMAs: the next group's fragments are read in front of a group, one
+                // of the two LDS-DMA issues of slab c + 2 follows every other group
+                u32x4 qh[2], ql[2];
+                auto read_q = [&](int gi, int slot) {
+                    const int st2 = gi >> 1, jt = 2 * nh + (gi & 1);
+                    qh[slot] = *reinterpret_cast<const u32x4 *>(slab + st2 * 8192 + (32 * jt + r) * 64 + off_h);
+                    ql[slot] = *reinterpret_cast<const u32x4 *>(slab + st2 * 8192 + (32 * jt + r) * 64 + off_l);
+                };
+                read_q(0, 0);
 #pragma unroll
-            for (int gi = 0; gi < 4; ++gi) {  // both column tiles whatever L is: branch-free (columns >= L are masked)
-                const int st2 = gi >> 1, k = gi & 1, sl = gi & 1;
-                if (gi + 1 < 4) read_q(gi + 1, sl ^ 1);
+                for (int gi = 0; gi < 4; ++gi) {  // both column tiles whatever L is: branch-free (columns >= L are masked)
+                    const int st2 = gi >> 1, k = gi & 1, sl = gi & 1;
+                    if (gi + 1 < 4) read_q(gi + 1, sl ^ 1);
 #if !defined(ARC_ABL) || ARC_ABL != 2
-                acc2[k] = ARC_MFMA(tl[st2], qh[sl], acc2[k]);
-                acc2[k] = ARC_MFMA(th[st2], ql[sl], acc2[k]);
-                acc2[k] = ARC_MFMA(th[st2], qh[sl], acc2[k]);
+                    acc2[k] = ARC_MFMA(tl[st2], qh[sl], acc2[k]);
+                    acc2[k] = ARC_MFMA(th[st2], ql[sl], acc2[k]);
+                    acc2[k] = ARC_MFMA(th[st2], qh[sl], acc2[k]);
 #else
-                acc2[k][0] += __uint_as_float(tl[st2][0] ^ qh[sl][0] ^ th[st2][1] ^ ql[sl][1]);
+                    acc2[k][0] += __uint_as_float(tl[st2][0] ^ qh[sl][0] ^ th[st2][1] ^ ql[sl][1]);
 #endif
-                ARC_PIN(acc2[k]);
-                if ((gi & 1) && c + DB < NT) arc_dma16(srcB[gi >> 1] + (long)(c + DB) * 128, ld + (gi >> 1) * 8192);
+                    ARC_PIN(acc2[k]);
+                    if ((gi & 1) && c + DB < NT) arc_dma16(srcB[gi >> 1] + (long)(c + DB) * 128, ld + (gi >> 1) * 8192);
+                }
+            } else if (c + DB < NT) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) arc_dma16(srcB[q] + (long)(c + DB) * 128, ld + q * 8192);
             }
             // the next chunk into the other patch, beside this chunk's MFMAs, by the half that holds it
 #if !defined(ARC_ABL) || ARC_ABL != 1
-            if (c + 1 < NT && nh == (c + 1) / NTW) convert(c + 1, (c + 1) % NTW);
+            if (c + 1 < NT && nh == (c + 1) / NTW && !dead) convert(c + 1, (c + 1) % NTW);
 #endif
         }
         ARC_STAMP(3 + 4 * s);
@@ -379,7 +399,9 @@ __global__ __launch_bounds__(512, 1) void arc_f16x3_kernel(ArcSplitArgs a) {
         auto cell_ok = [&](int k, int e) {
             return jbase + 32 * (2 * nh + k) + r < L && i0 + 32 * mt + acc_row(e, lane) < L;
         };
-        if (s == 0) {
+        if (idle) {
+            // nothing of this wave's cells is inside the sentence
+        } else if (s == 0) {
 #pragma unroll
             for (int k = 0; k < 2; ++k)
 #pragma unroll
@@ -533,13 +555,16 @@ static int launch_arc_split(const ArcSplitArgs &a, hipStream_t stream) {
     if (once.pending(&dev)) {
         if (hipFuncSetAttribute((const void *)arc_f16x3_kernel<NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 ArcSplitLayout<NT>::TOTAL) != hipSuccess ||
+            hipFuncSetAttribute((const void *)arc_f16x3_kernel<NT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                ArcSplitLayout<NT>::TOTAL) != hipSuccess ||
             hipFuncSetAttribute((const void *)arc_f16x3_kernel<NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 ArcSplitLayout<NT>::TOTAL) != hipSuccess)
             return fail(PHONLP_ERR_LAUNCH, "arc_scores_split: cannot raise the dynamic LDS limit");
         once.mark(dev);
     }
     ProfScope ps("arc_fused", stream);
-    if (a.L <= 128) hipLaunchKernelGGL((arc_f16x3_kernel<NT, false>), dim3(a.B), dim3(512), ArcSplitLayout<NT>::TOTAL, stream, a);
+    if (a.L <= 96) hipLaunchKernelGGL((arc_f16x3_kernel<NT, false, true>), dim3(a.B), dim3(512), ArcSplitLayout<NT>::TOTAL, stream, a);
+    else if (a.L <= 128) hipLaunchKernelGGL((arc_f16x3_kernel<NT, false>), dim3(a.B), dim3(512), ArcSplitLayout<NT>::TOTAL, stream, a);
     else hipLaunchKernelGGL((arc_f16x3_kernel<NT, true>), dim3(a.B, (a.L + 127) / 128), dim3(512), ArcSplitLayout<NT>::TOTAL, stream, a);
     return check_launch("arc_f16x3_kernel");
 }

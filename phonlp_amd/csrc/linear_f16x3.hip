@@ -1652,10 +1652,11 @@ int launch_linear_f16x3(const char *tag, const void *Xp, long pitch_x, const flo
             wide_once.mark(wdev);
         }
         a.num_n = ceil_div(N, 256);
-        // persistent form for the labels-at-heads epilogue: at least two tiles per workgroup, four pairs per tile
+        // persistent form for the labels-at-heads epilogue (four pairs per tile at least): a workgroup per CU, or per tile when there
+        // are fewer tiles than CUs (small batches: B = 1, L = 32 is 54 tiles -- two or three tiles per workgroup doubled its time)
         const int ntiles_w = a.num_m * a.num_n;
         if (at_heads->tile_ctr && (K16 >> 5) >= 4 && ntiles_w >= 16) {
-            const int cap = persist_cus(), want = (ntiles_w / 2) & ~7;
+            const int cap = persist_cus(), want = (ntiles_w + 7) & ~7;
             if (cap < 0) return fail(PHONLP_ERR_LAUNCH, "linear_split: cannot set up the persistent stage A");
             a.tile_ctr = at_heads->tile_ctr;
             ProfScope psh(tag, stream);
