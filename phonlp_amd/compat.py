@@ -338,12 +338,98 @@ def _dev_loss(self, batch_dep=None, batch_pos=None, batch_ner=None, lambda_pos=1
     return loss.item(), l_pos.item(), l_ner.item(), l_dep.item()
 
 
-def patch_trainer(trainer, device=None, move_encoder=True):
+# --------------------------------------------------------------------------------------------------- autograd seam
+class _HeadLossFn(torch.autograd.Function):
+    """One of the three training losses as a node of a PyTorch graph: forward = the HIP heads' loss value, backward = the
+    gradients the HIP kernels computed for the gathered encoder rows and for every head parameter the loss reaches
+    (TaskHeads.parser_backward / pos_backward / ner_backward: what autograd derives from ref jointmodel/model.py:107-236).
+    Both are computed in forward() -- the kernels keep no graph -- and backward() scales them by the incoming gradient."""
+
+    @staticmethod
+    def forward(ctx, enc, run, names, *params):
+        out = run(enc.detach())
+        ctx.names, ctx.grads, ctx.d_enc = names, out["grads"], out["d_enc"]
+        ctx.meta = [(p.shape, p.device, p.dtype) for p in params]
+        ctx.enc_meta = (enc.device, enc.dtype)
+        return out["loss"].detach().reshape(()).clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        d_enc = (ctx.d_enc * g.to(ctx.d_enc.device)).to(device=ctx.enc_meta[0], dtype=ctx.enc_meta[1])
+        outs = []
+        for name, (shape, dev, dt) in zip(ctx.names, ctx.meta):
+            gr = ctx.grads.get(name)
+            outs.append(None if gr is None else (gr * g.to(gr.device)).reshape(shape).to(device=dev, dtype=dt))
+        return (d_enc, None, None, *outs)
+
+
+def _loss_node(run, enc, params):
+    names = tuple(params.keys())
+    return _HeadLossFn.apply(enc, run, names, *[params[k] for k in names])
+
+
+def parser_loss(heads, params, enc, sentlens, head, deprel, number_of_words=None):
+    """Differentiable `loss` of ref jointmodel/model.py:162-236 (dep_forward, eval=False, every dropout the identity) from the
+    gathered encoder rows `enc` [B, L, E].  `params`: {reference parameter name: the live parameter} of the head modules
+    (e.g. dict(model.named_parameters()) without the encoder's); `heads` must hold the same values (refresh_heads).
+    loss.backward() then leaves in every parameter's .grad, and sends into `enc`, what the reference's own backward does."""
+    run = lambda e: (lambda o: {**o, "loss": o["loss"][4]})(heads.parser_backward(e, sentlens, head, deprel, number_of_words))
+    return _loss_node(run, enc, params)
+
+
+def pos_loss(heads, params, enc, sentlens, upos, ignore_index=1):
+    """Differentiable `loss` of ref jointmodel/model.py:107-135 (pos_forward, use_soft_pos=False)."""
+    run = lambda e: (lambda o: {**o, "loss": o["loss"][0]})(heads.pos_backward(e, sentlens, upos, ignore_index))
+    return _loss_node(run, enc, params)
+
+
+def ner_loss(heads, params, enc, sentlens, tags):
+    """Differentiable `loss` of ref jointmodel/model.py:139-160 (ner_forward: CRF NLL averaged over the batch)."""
+    return _loss_node(lambda e: heads.ner_backward(e, sentlens, tags), enc, params)
+
+
+def _encode_train(model, tokens, first_subword):
+    """Encoder + first-sub-word gather with autograd through both (ref jointmodel/model.py:112-116)."""
+    dev = _dev()
+    enc_dev = next(model.phobert.parameters()).device
+    emb = model.phobert(tokens.to(enc_dev))[2][-1]
+    idx = first_subword.to(enc_dev).long().unsqueeze(-1).expand(-1, -1, emb.shape[-1])
+    return torch.gather(emb, 1, idx).float().to(dev)
+
+
+def _update(self, batch_dep=None, batch_pos=None, batch_ner=None, lambda_pos=1.0, lambda_ner=1.0, lambda_dep=1.0):
+    """ref trainer.py:62-99 with the three heads' losses AND their backward on the HIP path: same batches, lambdas and
+    return value; after it every head parameter's .grad and the encoder's hold what the reference's loss.backward()
+    leaves there.  The heads' dropouts must be off (args `dropout` = `word_dropout` = 0): the kernels take no masks yet --
+    with them on, keep the reference's own update().  The encoder trains as it is (its dropout included)."""
+    args = self.model.args
+    if float(args.get("dropout", 0.0)) != 0.0 or float(args.get("word_dropout", 0.0)) != 0.0:
+        raise NotImplementedError("phonlp_amd update(): head dropout / word dropout must be 0 (no mask inputs yet)")
+    self.model.train()
+    h = refresh_heads(self.model)
+    params = {k: p for k, p in self.model.named_parameters() if not k.startswith("phobert.")}
+    if "dep_hid.weight" not in params:  # a model that keeps its heads outside the module tree (tests/stub_model.py)
+        params = {k: v for k, v in _head_state(self.model).items() if v.requires_grad}
+    tok, fsw, _, head, rel, nwords, _, lens = batch_dep[:8]
+    l_dep = parser_loss(h, params, _encode_train(self.model, tok, fsw), lens, head, rel, nwords)
+    tok, fsw, upos, _, lens = batch_pos[:5]
+    l_pos = pos_loss(h, params, _encode_train(self.model, tok, fsw), lens, upos)
+    tok, fsw, _, tags, _, lens = batch_ner[:6]
+    l_ner = ner_loss(h, params, _encode_train(self.model, tok, fsw), lens, tags)
+    loss = lambda_pos * l_pos + lambda_ner * l_ner + lambda_dep * l_dep
+    vals = (loss.item(), l_pos.item(), l_ner.item(), l_dep.item())
+    loss.backward()
+    return vals
+
+
+def patch_trainer(trainer, device=None, move_encoder=True, train_seam=False):
     """The evaluation-loop twin of patch(): rebinds `predict_dep`, `predict_pos` and `predict_ner` of a reference
     `JointTrainer` (models/jointmodel/trainer.py) so that the dev/test scoring loops of the training script run the
     heads and decoders on the MI355X, and adds `dev_loss` (the loss values of `update` on held-out batches).  `trainer.model` (jointmodel/model.py JointModel) keeps its encoder and its
     training-mode forward; only the eval-mode seams change.  The seams follow the live parameters: they re-pack the
-    head weights (refresh_heads) when an optimizer step or load_state_dict changed them since the last call."""
+    head weights (refresh_heads) when an optimizer step or load_state_dict changed them since the last call.
+    `train_seam=True` also rebinds `update` (trainer.py:62-99): the three losses and their backward through the heads on
+    the HIP path as autograd nodes (head dropouts must be 0)."""
     dev = device or _dev()
     model = trainer.model
     if move_encoder:
@@ -353,6 +439,8 @@ def patch_trainer(trainer, device=None, move_encoder=True):
     trainer.predict_pos = types.MethodType(_predict_pos, trainer)
     trainer.predict_ner = types.MethodType(_predict_ner, trainer)
     trainer.dev_loss = types.MethodType(_dev_loss, trainer)  # no counterpart by name: `update` minus dropout and backward
+    if train_seam:
+        trainer.update = types.MethodType(_update, trainer)
     return trainer
 
 

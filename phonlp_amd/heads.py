@@ -325,7 +325,7 @@ class TaskHeads:
         """Backward of the parser loss (ref jointmodel/model.py:162-236, model in .eval()) through the four scorers and
         dep_hid -> {"grads": {reference parameter name: gradient in the reference's shape} for `unlabeled` / `deprel` /
         `linearization` / `distance` (.W1 / .W2 .weight, .bias, .scorer.W_bilin.weight), `dep_hid`, `upos_emb_matrix_dep`,
-        `upos_hid`, `upos_clf`; "d_hidden": the gradient w.r.t. dep_hid's output [B,L,D]; "d_feat": w.r.t. its input
+        `upos_hid`, `upos_clf`; "loss": fp32 [5] as parser_loss; "d_hidden": the gradient w.r.t. dep_hid's output [B,L,D]; "d_feat": w.r.t. its input
         [B,L,D] (= [enc ; pos_emb]; padded rows zero: the reference's padding is a constant); "d_enc": w.r.t. the
         gathered encoder rows [B,L,E], both routes added}.  Un-folded weights (the folds are an inference-time rewrite)."""
         w = self.w
@@ -345,6 +345,7 @@ class TaskHeads:
         XF, T = ops.label_project(hidden, w.lab_W12, w.lab_b12, w.lab_Wbt, H, O)
         nw = float(lens.sum().item()) if number_of_words is None else float(number_of_words)
         use_lin, use_dist = w.linearization and n > 1, w.distance and n > 1
+        loss = ops.dep_loss(dep["arc_logp"], dep.get("raw"), T, XF, gh, gr, lens, H, O, use_lin, use_dist, nw)
         d_arc, d_label, d_lin, d_dist = ops.dep_loss_grad(dep["arc_logp"], dep.get("raw"), T, XF, gh, gr, lens, H, O,
                                                           use_lin, use_dist, nw)
         hm = hidden.reshape(M, D)
@@ -393,7 +394,7 @@ class TaskHeads:
                                                     w.emb_dep, d_feat[:, E:])
         grads["upos_emb_matrix_dep"] = d_emb
         grads.update(g_pos)
-        return {"grads": grads, "d_hidden": d_hidden, "d_feat": d_feat.view(B, L, D),
+        return {"loss": loss, "grads": grads, "d_hidden": d_hidden, "d_feat": d_feat.view(B, L, D),
                 "d_enc": (d_feat[:, :E] + d_x).view(B, L, E)}
 
     # ---- training model's pos_forward(use_soft_pos=False) after the gather, loss value only (ref jointmodel/model.py:128-135)
@@ -421,7 +422,7 @@ class TaskHeads:
 
     # ---- the NER loss's backward (ref jointmodel/model.py:139-160 + crf.py:24-46 under loss.backward(), model in .eval())
     def ner_backward(self, enc: torch.Tensor, sentlens, gold_tags):
-        """-> {"grads": {"ner_tag_clf.weight", "ner_tag_clf.bias", "crit_ner._transitions", "upos_emb_matrix_ner",
+        """-> {"loss": the batch-averaged CRF NLL (0-dim), "grads": {"ner_tag_clf.weight", "ner_tag_clf.bias", "crit_ner._transitions", "upos_emb_matrix_ner",
         "upos_hid.*", "upos_clf.*"}, "d_enc": the gradient w.r.t. the gathered encoder rows [B,L,E]}: CRF NLL averaged
         over the batch -> ReLU -> ner_tag_clf -> [enc ; soft POS embedding] -> the POS layers."""
         w = self.w
@@ -431,6 +432,8 @@ class TaskHeads:
         M, D = B * L, feat.shape[2]
         gold = torch.as_tensor(gold_tags).to(device=enc.device, dtype=torch.int32).contiguous()
         d_logits, d_trans = ops.crf_nll_grad(logits.contiguous(), w.trans, None, lens, gold, 1.0 / B)
+        ln, un, bi = ops.crf_log_partition(logits.contiguous(), w.trans, None, lens, gold)
+        loss = (-(un + bi - ln)).sum() / B  # CRFLoss with batch_average (ref crf.py:39-42)
         T = logits.shape[2]
         d_feat, dWn, dbn = ops.linear_backward(feat.reshape(M, D).contiguous(), w.ner_w, logits.reshape(M, T).contiguous(),
                                                d_logits.reshape(M, T).contiguous(), True)
@@ -438,7 +441,7 @@ class TaskHeads:
                                                     w.emb_ner, d_feat[:, E:])
         grads = {"ner_tag_clf.weight": dWn, "ner_tag_clf.bias": dbn, "crit_ner._transitions": d_trans,
                  "upos_emb_matrix_ner": d_emb, **g_pos}
-        return {"grads": grads, "d_enc": (d_feat[:, :E] + d_x).view(B, L, E)}
+        return {"loss": loss, "grads": grads, "d_enc": (d_feat[:, :E] + d_x).view(B, L, E)}
 
     # ---- ... and its backward through upos_clf and upos_hid (what loss.backward() leaves behind pos_forward)
     def pos_backward(self, enc: torch.Tensor, sentlens, gold_upos, ignore_index=1):
