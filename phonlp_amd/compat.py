@@ -368,24 +368,25 @@ def _loss_node(run, enc, params):
     return _HeadLossFn.apply(enc, run, names, *[params[k] for k in names])
 
 
-def parser_loss(heads, params, enc, sentlens, head, deprel, number_of_words=None):
+def parser_loss(heads, params, enc, sentlens, head, deprel, number_of_words=None, masks=None):
     """Differentiable `loss` of ref jointmodel/model.py:162-236 (dep_forward, eval=False, every dropout the identity) from the
     gathered encoder rows `enc` [B, L, E].  `params`: {reference parameter name: the live parameter} of the head modules
     (e.g. dict(model.named_parameters()) without the encoder's); `heads` must hold the same values (refresh_heads).
-    loss.backward() then leaves in every parameter's .grad, and sends into `enc`, what the reference's own backward does."""
-    run = lambda e: (lambda o: {**o, "loss": o["loss"][4]})(heads.parser_backward(e, sentlens, head, deprel, number_of_words))
+    loss.backward() then leaves in every parameter's .grad, and sends into `enc`, what the reference's own backward does.
+    `masks` (TaskHeads._parser_backward_train): the model in .train(), the dropout masks drawn by the caller."""
+    run = lambda e: (lambda o: {**o, "loss": o["loss"][4]})(heads.parser_backward(e, sentlens, head, deprel, number_of_words, masks))
     return _loss_node(run, enc, params)
 
 
-def pos_loss(heads, params, enc, sentlens, upos, ignore_index=1):
+def pos_loss(heads, params, enc, sentlens, upos, ignore_index=1, masks=None):
     """Differentiable `loss` of ref jointmodel/model.py:107-135 (pos_forward, use_soft_pos=False)."""
-    run = lambda e: (lambda o: {**o, "loss": o["loss"][0]})(heads.pos_backward(e, sentlens, upos, ignore_index))
+    run = lambda e: (lambda o: {**o, "loss": o["loss"][0]})(heads.pos_backward(e, sentlens, upos, ignore_index, masks))
     return _loss_node(run, enc, params)
 
 
-def ner_loss(heads, params, enc, sentlens, tags):
+def ner_loss(heads, params, enc, sentlens, tags, masks=None):
     """Differentiable `loss` of ref jointmodel/model.py:139-160 (ner_forward: CRF NLL averaged over the batch)."""
-    return _loss_node(lambda e: heads.ner_backward(e, sentlens, tags), enc, params)
+    return _loss_node(lambda e: heads.ner_backward(e, sentlens, tags, masks), enc, params)
 
 
 def _encode_train(model, tokens, first_subword):
@@ -397,25 +398,57 @@ def _encode_train(model, tokens, first_subword):
     return torch.gather(emb, 1, idx).float().to(dev)
 
 
+def draw_masks(heads, task, B, L, sentlens, p_drop, p_word, device, generator=None):
+    """The random masks of one training step of one task, drawn as the reference's modules draw them (independent Bernoulli
+    draws: WordDropout `rand < p` per live word, models/common/dropout.py:19-21; nn.Dropout keeps with 1 - p and scales by
+    1 / (1 - p)), in the layout TaskHeads.*_backward(masks=...) takes.  task: "parser" | "ner" | "pos"."""
+    w = heads.w
+    lens = torch.as_tensor(list(sentlens) if not isinstance(sentlens, torch.Tensor) else sentlens).to(device)
+    live = torch.arange(L, device=device)[None, :] < lens[:, None]
+    rnd = lambda *shape: torch.rand(*shape, device=device, generator=generator)
+    word = lambda: (rnd(B, L) < p_word) & live
+    drop = lambda n: (rnd(B, L, n) >= p_drop).float() / max(1.0 - p_drop, 1e-12)
+    Hp = w.upos_hid_w.shape[0]
+    masks = {"wd_pos": word(), "drop_pos": drop(Hp)}
+    if task in ("parser", "ner"):
+        masks["wd"] = word()
+    if task == "parser":
+        D = w.dep_hid_w.shape[0]
+        names = ("unlabeled", "deprel", "linearization", "distance")
+        masks["hidden"] = {n: (drop(D), drop(D)) for n in names}
+        masks["scorer"] = {n: (drop(w.H), drop(w.H)) for n in names}
+    return masks
+
+
 def _update(self, batch_dep=None, batch_pos=None, batch_ner=None, lambda_pos=1.0, lambda_ner=1.0, lambda_dep=1.0):
     """ref trainer.py:62-99 with the three heads' losses AND their backward on the HIP path: same batches, lambdas and
     return value; after it every head parameter's .grad and the encoder's hold what the reference's loss.backward()
-    leaves there.  The heads' dropouts must be off (args `dropout` = `word_dropout` = 0): the kernels take no masks yet --
-    with them on, keep the reference's own update().  The encoder trains as it is (its dropout included)."""
+    leaves there.  The heads' dropouts (args `dropout`, `word_dropout`) act through masks drawn here per step
+    (draw_masks) and handed to the kernels' callers as inputs; the encoder trains as it is (its own dropout included)."""
     args = self.model.args
-    if float(args.get("dropout", 0.0)) != 0.0 or float(args.get("word_dropout", 0.0)) != 0.0:
-        raise NotImplementedError("phonlp_amd update(): head dropout / word dropout must be 0 (no mask inputs yet)")
+    p_drop, p_word = float(args.get("dropout", 0.0)), float(args.get("word_dropout", 0.0))
     self.model.train()
     h = refresh_heads(self.model)
+    dev = h.w.trans.device
     params = {k: p for k, p in self.model.named_parameters() if not k.startswith("phobert.")}
     if "dep_hid.weight" not in params:  # a model that keeps its heads outside the module tree (tests/stub_model.py)
         params = {k: v for k, v in _head_state(self.model).items() if v.requires_grad}
+    train = p_drop > 0.0 or p_word > 0.0
+    if train and h.w.repl_dep is None:
+        raise ValueError("phonlp_amd update(): word dropout needs the training model's drop_replacement_* parameters")
+
+    def masks(task, enc, lens):
+        return draw_masks(h, task, enc.shape[0], enc.shape[1], lens, p_drop, p_word, dev) if train else None
+
     tok, fsw, _, head, rel, nwords, _, lens = batch_dep[:8]
-    l_dep = parser_loss(h, params, _encode_train(self.model, tok, fsw), lens, head, rel, nwords)
+    enc = _encode_train(self.model, tok, fsw)
+    l_dep = parser_loss(h, params, enc, lens, head, rel, nwords, masks("parser", enc, lens))
     tok, fsw, upos, _, lens = batch_pos[:5]
-    l_pos = pos_loss(h, params, _encode_train(self.model, tok, fsw), lens, upos)
+    enc = _encode_train(self.model, tok, fsw)
+    l_pos = pos_loss(h, params, enc, lens, upos, masks=masks("pos", enc, lens))
     tok, fsw, _, tags, _, lens = batch_ner[:6]
-    l_ner = ner_loss(h, params, _encode_train(self.model, tok, fsw), lens, tags)
+    enc = _encode_train(self.model, tok, fsw)
+    l_ner = ner_loss(h, params, enc, lens, tags, masks("ner", enc, lens))
     loss = lambda_pos * l_pos + lambda_ner * l_ner + lambda_dep * l_dep
     vals = (loss.item(), l_pos.item(), l_ner.item(), l_dep.item())
     loss.backward()
@@ -429,7 +462,7 @@ def patch_trainer(trainer, device=None, move_encoder=True, train_seam=False):
     training-mode forward; only the eval-mode seams change.  The seams follow the live parameters: they re-pack the
     head weights (refresh_heads) when an optimizer step or load_state_dict changed them since the last call.
     `train_seam=True` also rebinds `update` (trainer.py:62-99): the three losses and their backward through the heads on
-    the HIP path as autograd nodes (head dropouts must be 0)."""
+    the HIP path as autograd nodes, the heads' dropout masks drawn per step and passed in."""
     dev = device or _dev()
     model = trainer.model
     if move_encoder:

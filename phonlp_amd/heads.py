@@ -78,6 +78,10 @@ class HeadWeights:
     arc_bound: Optional[tuple] = None
     arc_Wbq_s: Optional[tuple] = None
     arc_pad_img: Optional[tuple] = None  # (planes [1, S*2*KC*4], inverse scale as a float)
+    # word dropout's replacement vectors (training model only, ref jointmodel/model.py:27-35); None for an annotate model
+    repl_pos: Optional[torch.Tensor] = None
+    repl_ner: Optional[torch.Tensor] = None
+    repl_dep: Optional[torch.Tensor] = None
 
     @classmethod
     def from_state_dict(cls, sd: Dict[str, torch.Tensor], device="cuda", linearization=True, distance=True):
@@ -177,6 +181,9 @@ class HeadWeights:
             lab_ones_col=lab[2][:, H].contiguous(),
             arc_W12p_s=tuple(ops.split_rows(arcp)), lab_W12p_s=tuple(ops.split_rows(labp)),
             emb_eye=torch.eye(U_, Up, dtype=torch.float32, device=device).contiguous(),
+            repl_pos=g("drop_replacement_pos") if "drop_replacement_pos" in sd else None,
+            repl_ner=g("drop_replacement_ner") if "drop_replacement_ner" in sd else None,
+            repl_dep=g("drop_replacement_dep") if "drop_replacement_dep" in sd else None,
             **fused_arc,
         )
 
@@ -321,13 +328,16 @@ class TaskHeads:
         return {"d_unlabeled": d_arc, "d_label": d_label, "d_lin": d_lin, "d_dist": d_dist}
 
     # ---- ... and on through the scorers and dep_hid: what loss.backward() leaves in the parameters' .grad
-    def parser_backward(self, enc: torch.Tensor, sentlens, gold_head, gold_rel, number_of_words=None):
+    def parser_backward(self, enc: torch.Tensor, sentlens, gold_head, gold_rel, number_of_words=None, masks=None):
         """Backward of the parser loss (ref jointmodel/model.py:162-236, model in .eval()) through the four scorers and
         dep_hid -> {"grads": {reference parameter name: gradient in the reference's shape} for `unlabeled` / `deprel` /
         `linearization` / `distance` (.W1 / .W2 .weight, .bias, .scorer.W_bilin.weight), `dep_hid`, `upos_emb_matrix_dep`,
         `upos_hid`, `upos_clf`; "loss": fp32 [5] as parser_loss; "d_hidden": the gradient w.r.t. dep_hid's output [B,L,D]; "d_feat": w.r.t. its input
         [B,L,D] (= [enc ; pos_emb]; padded rows zero: the reference's padding is a constant); "d_enc": w.r.t. the
-        gathered encoder rows [B,L,E], both routes added}.  Un-folded weights (the folds are an inference-time rewrite)."""
+        gathered encoder rows [B,L,E], both routes added}.  Un-folded weights (the folds are an inference-time rewrite).
+        `masks`: the model in .train(), see _parser_backward_train."""
+        if masks is not None:
+            return self._parser_backward_train(enc, sentlens, gold_head, gold_rel, number_of_words, masks)
         w = self.w
         n = w.n_arc_scorers
         dep = self.parser(enc, sentlens, want_raw=n > 1, want_label_argmax=False)
@@ -397,6 +407,142 @@ class TaskHeads:
         return {"loss": loss, "grads": grads, "d_hidden": d_hidden, "d_feat": d_feat.view(B, L, D),
                 "d_enc": (d_feat[:, :E] + d_x).view(B, L, E)}
 
+    # ---- the same three backward passes with the model in .train(): dropout masks as INPUTS
+    @staticmethod
+    def _word_drop(x, m, repl):
+        """WordDropout (ref models/common/dropout.py:15-27): the rows m of x [M, D] replaced by the vector repl."""
+        return torch.where(m.reshape(-1, 1), repl.reshape(1, -1).expand_as(x), x).contiguous()
+
+    @staticmethod
+    def _soft_pos_train(w, x, emb, m_wd, m_drop):
+        """pos_forward(use_soft_pos=True) in .train() (ref jointmodel/model.py:125-137): word dropout on the encoder rows x [M,E]
+        (rows m_wd -> drop_replacement_pos), ReLU(upos_hid), dropout mask m_drop [M,Hp] (kept entries 1/(1-p)), upos_clf,
+        softmax, @ emb.  w: the HeadWeights.  -> (pos_emb [M,TE], upos logits, backward(d_pos_emb) -> (d_x, d_emb, {gradients}))."""
+        xp = TaskHeads._word_drop(x, m_wd, w.repl_pos)
+        hid = ops.linear(xp, w.upos_hid_w, w.upos_hid_b, True, None, 0)
+        hid_d = (hid * m_drop).contiguous()
+        logits = ops.linear(hid_d, w.upos_clf_w, w.upos_clf_b, False, None, 0)
+        P = ops.softmax_rows(logits.contiguous())
+        U = P.shape[1]
+        U4 = (U + 3) // 4 * 4  # (the dense-layer kernels take reduction lengths that are multiples of 4)
+        pos_emb = ops.linear(torch.nn.functional.pad(P, (0, U4 - U)).contiguous(),
+                             torch.nn.functional.pad(emb.t(), (0, U4 - U)).contiguous(), None, False, None, 0)
+
+        def backward(d_pos_emb):
+            d_P, d_embT, _ = ops.linear_backward(P, emb.t().contiguous(), None, d_pos_emb.contiguous(), False, need_db=False)
+            d_logits = ops.softmax_rows_backward(P, d_P)
+            d_hid_d, dWc, dbc = ops.linear_backward(hid_d, w.upos_clf_w, None, d_logits, False)
+            d_xp, dWh, dbh = ops.linear_backward(xp, w.upos_hid_w, hid, (d_hid_d * m_drop).contiguous(), True)
+            keep = (~m_wd).reshape(-1, 1).to(d_xp.dtype)
+            g = {"upos_hid.weight": dWh, "upos_hid.bias": dbh, "upos_clf.weight": dWc, "upos_clf.bias": dbc,
+                 "drop_replacement_pos": (d_xp * (1.0 - keep)).sum(0)}
+            return d_xp * keep, d_embT.t().contiguous(), g
+        return pos_emb, logits, backward
+
+    def _parser_backward_train(self, enc, sentlens, gold_head, gold_rel, number_of_words, masks):
+        """dep_forward(eval=False) of the training model in .train() (ref jointmodel/model.py:162-236) and its backward, the
+        random masks given by the caller in the padded layout: masks = {"wd_pos": bool [B,L] (word dropout in front of the
+        POS layers), "drop_pos": [B,L,Hp] (nn.Dropout behind ReLU(upos_hid); kept entries carry 1/(1-p)), "wd": bool [B,L]
+        (word dropout on [enc ; pos_emb]), "hidden": {scorer name: (m1, m2)} each [B,L,D] (the eight drop_dep draws on
+        dep_hid's output, :185-200), "scorer": {scorer name: (m1, m2)} each [B,L,H] (the scorers' own dropout behind
+        ReLU(W1 .) / ReLU(W2 .), biaffine.py:82-85)}; scorer names unlabeled / deprel / linearization / distance.
+        Every dense product runs on the library's kernels; the masks are elementwise products between them."""
+        w = self.w
+        n = w.n_arc_scorers
+        lens = as_sentlens(sentlens, enc.device)
+        B, L, E = enc.shape
+        M, H, O, KP = B * L, w.H, w.O, ops.kp(w.H)
+        D = w.dep_hid_w.shape[0]
+        dev = enc.device
+        f32 = lambda t: torch.as_tensor(t).to(device=dev, dtype=torch.float32)
+        bl = lambda t: torch.as_tensor(t).to(device=dev, dtype=torch.bool).reshape(M)
+
+        def with_root(t):
+            t = torch.as_tensor(t).to(device=dev, dtype=torch.int32)
+            if t.shape[1] == L - 1:
+                t = torch.nn.functional.pad(t, (1, 0))
+            return t.contiguous()
+
+        gh, gr = with_root(gold_head), with_root(gold_rel)
+        live = (torch.arange(L, device=dev)[None, :] < lens[:, None]).reshape(M, 1)
+        x = enc.reshape(M, E).contiguous()
+        pos_emb, _, pos_bw = TaskHeads._soft_pos_train(w, x, w.emb_dep, bl(masks["wd_pos"]), f32(masks["drop_pos"]).reshape(M, -1))
+        feat = torch.cat([x, pos_emb], 1).contiguous()
+        m_wd = bl(masks["wd"])
+        featd = TaskHeads._word_drop(feat, m_wd, w.repl_dep)
+        # dep_hid; the padded rows of its output are the zeros of pad_packed_sequence (:182-183)
+        hidden = (ops.linear(featd, w.dep_hid_w, w.dep_hid_b, False, None, 0) * live).contiguous()
+
+        def first_layer(name, W12, b12, row0):
+            """A scorer's X1' | X2' [M, 2KP] from its two masked copies of `hidden`, plus what its backward needs."""
+            mh, ms = masks["hidden"][name], masks["scorer"][name]
+            out = torch.empty((M, 2 * KP), dtype=torch.float32, device=dev)
+            saved = []
+            for k in range(2):
+                hin = (hidden * f32(mh[k]).reshape(M, D)).contiguous()
+                Wk, bk = W12[row0 + k * KP:row0 + (k + 1) * KP].contiguous(), b12[row0 + k * KP:row0 + (k + 1) * KP].contiguous()
+                mk = torch.ones((M, KP), dtype=torch.float32, device=dev)  # the ones column (appended behind the dropout) stays
+                mk[:, :H] = f32(ms[k]).reshape(M, H)
+                y = (ops.linear(hin, Wk, bk, True, None, 0) * mk).contiguous()
+                out[:, k * KP:(k + 1) * KP] = y
+                saved.append((hin, Wk, mk, y, f32(mh[k]).reshape(M, D)))
+            return out, saved
+
+        names = [nm for nm, on in zip(SCORERS, (True, w.linearization and n > 1, w.distance and n > 1)) if on]
+        XFa = torch.zeros((M, n * 2 * KP), dtype=torch.float32, device=dev)
+        saved_arc = {}
+        for s_, nm in enumerate(SCORERS[:n]):
+            if nm in names:
+                XFa[:, s_ * 2 * KP:(s_ + 1) * 2 * KP], saved_arc[nm] = first_layer(nm, w.arc_W12, w.arc_b12, s_ * 2 * KP)
+        use_lin, use_dist = "linearization" in names, "distance" in names
+        arc_logp, raw = ops.biaffine_arc_scores_raw(XFa, B, L, w.arc_Wbt, H, n, use_lin, use_dist)
+        XF, saved_lab = first_layer("deprel", w.lab_W12, w.lab_b12, 0)
+        T = ops.linear(XF[:, :KP].contiguous(), w.lab_Wbt, None, False, None, 0)
+        nw = float(lens.sum().item()) if number_of_words is None else float(number_of_words)
+        raw_in = raw if n > 1 else None
+        loss = ops.dep_loss(arc_logp, raw_in, T, XF, gh, gr, lens, H, O, use_lin, use_dist, nw)
+        d_arc, d_label, d_lin, d_dist = ops.dep_loss_grad(arc_logp, raw_in, T, XF, gh, gr, lens, H, O, use_lin, use_dist, nw)
+        at_head = lambda v: torch.zeros((B, L, L), dtype=torch.float32, device=dev).scatter_(2, gh.long().unsqueeze(2), v.unsqueeze(2))
+        Gs = {"unlabeled": d_arc, "linearization": at_head(d_lin) if use_lin else None, "distance": at_head(d_dist) if use_dist else None}
+        grads = {}
+
+        def unpack_bilinear(dWbt, Ox):
+            return dWbt.view(Ox, KP, KP)[:, :H + 1, :H + 1].permute(2, 0, 1).contiguous().view(H + 1, H + 1, Ox)
+
+        d_hidden = torch.zeros((M, D), dtype=torch.float32, device=dev)
+
+        def first_layer_backward(name, dXF_s, saved):
+            nonlocal d_hidden
+            for k, wn in enumerate(("W1", "W2")):
+                hin, Wk, mk, y, mhk = saved[k]
+                dY = (dXF_s[:, k * KP:(k + 1) * KP] * mk).contiguous()
+                d_hin, dW, db = ops.linear_backward(hin, Wk, y, dY, True)
+                grads[f"{name}.{wn}.weight"], grads[f"{name}.{wn}.bias"] = dW[:H], db[:H]
+                d_hidden = d_hidden + d_hin * mhk
+
+        for s_, nm in enumerate(SCORERS[:n]):
+            if nm not in names:
+                continue
+            c0 = s_ * 2 * KP
+            dXF_s, dWbt_s = ops.bilinear_backward(XFa[:, c0:c0 + 2 * KP].contiguous(), w.arc_Wbt[s_ * KP:(s_ + 1) * KP].contiguous(),
+                                                  Gs[nm].contiguous(), H)
+            grads[f"{nm}.scorer.W_bilin.weight"] = unpack_bilinear(dWbt_s, 1)
+            first_layer_backward(nm, dXF_s, saved_arc[nm])
+        dXFl, dWbtl = ops.label_backward(XF, w.lab_Wbt, d_label, gh, lens, H, O, T)
+        grads["deprel.scorer.W_bilin.weight"] = unpack_bilinear(dWbtl, O)
+        first_layer_backward("deprel", dXFl, saved_lab)
+        d_live = (d_hidden * live).contiguous()
+        d_featd, dWd, dbd = ops.linear_backward(featd, w.dep_hid_w, None, d_live, False)
+        grads["dep_hid.weight"], grads["dep_hid.bias"] = dWd, dbd
+        keep = (~m_wd).reshape(M, 1).to(torch.float32)
+        grads["drop_replacement_dep"] = (d_featd * (1.0 - keep)).sum(0)
+        d_feat = d_featd * keep
+        d_x, d_emb, g_pos = pos_bw(d_feat[:, E:].contiguous())
+        grads["upos_emb_matrix_dep"] = d_emb
+        grads.update(g_pos)
+        return {"loss": loss, "grads": grads, "d_hidden": d_hidden.view(B, L, D), "d_feat": d_feat.view(B, L, -1),
+                "d_enc": (d_feat[:, :E] + d_x).view(B, L, E)}
+
     # ---- training model's pos_forward(use_soft_pos=False) after the gather, loss value only (ref jointmodel/model.py:128-135)
     def pos_loss(self, enc: torch.Tensor, sentlens, gold_upos, ignore_index=1) -> torch.Tensor:
         """-> fp32 [3] on the device: mean cross-entropy (what the reference returns as `loss`), sum, words counted."""
@@ -421,11 +567,37 @@ class TaskHeads:
                                               "upos_clf.bias": dbc}
 
     # ---- the NER loss's backward (ref jointmodel/model.py:139-160 + crf.py:24-46 under loss.backward(), model in .eval())
-    def ner_backward(self, enc: torch.Tensor, sentlens, gold_tags):
+    def ner_backward(self, enc: torch.Tensor, sentlens, gold_tags, masks=None):
         """-> {"loss": the batch-averaged CRF NLL (0-dim), "grads": {"ner_tag_clf.weight", "ner_tag_clf.bias", "crit_ner._transitions", "upos_emb_matrix_ner",
         "upos_hid.*", "upos_clf.*"}, "d_enc": the gradient w.r.t. the gathered encoder rows [B,L,E]}: CRF NLL averaged
-        over the batch -> ReLU -> ner_tag_clf -> [enc ; soft POS embedding] -> the POS layers."""
+        over the batch -> ReLU -> ner_tag_clf -> [enc ; soft POS embedding] -> the POS layers.  `masks` (model in .train()):
+        {"wd_pos", "drop_pos"} as in _parser_backward_train and "wd": bool [B,L], the word dropout on [enc ; pos_emb] (:155)."""
         w = self.w
+        if masks is not None:
+            lens = as_sentlens(sentlens, enc.device)
+            B, L, E = enc.shape
+            M, dev = B * L, enc.device
+            bl = lambda t: torch.as_tensor(t).to(device=dev, dtype=torch.bool).reshape(M)
+            live = (torch.arange(L, device=dev)[None, :] < lens[:, None]).reshape(M, 1)
+            x = enc.reshape(M, E).contiguous()
+            pos_emb, _, pos_bw = TaskHeads._soft_pos_train(w, x, w.emb_ner, bl(masks["wd_pos"]),
+                                                           torch.as_tensor(masks["drop_pos"]).to(dev, torch.float32).reshape(M, -1))
+            m_wd = bl(masks["wd"])
+            featd = TaskHeads._word_drop(torch.cat([x, pos_emb], 1).contiguous(), m_wd, w.repl_ner)
+            logits2 = (ops.linear(featd, w.ner_w, w.ner_b, True, None, 0) * live).contiguous()
+            T = logits2.shape[1]
+            logits = logits2.view(B, L, T)
+            gold = torch.as_tensor(gold_tags).to(device=dev, dtype=torch.int32).contiguous()
+            d_logits, d_trans = ops.crf_nll_grad(logits, w.trans, None, lens, gold, 1.0 / B)
+            ln, un, bi = ops.crf_log_partition(logits, w.trans, None, lens, gold)
+            loss = (-(un + bi - ln)).sum() / B
+            d_featd, dWn, dbn = ops.linear_backward(featd, w.ner_w, logits2, d_logits.reshape(M, T).contiguous(), True)
+            keep = (~m_wd).reshape(M, 1).to(torch.float32)
+            d_feat = d_featd * keep
+            d_x, d_emb, g_pos = pos_bw(d_feat[:, E:].contiguous())
+            grads = {"ner_tag_clf.weight": dWn, "ner_tag_clf.bias": dbn, "crit_ner._transitions": d_trans,
+                     "upos_emb_matrix_ner": d_emb, "drop_replacement_ner": (d_featd * (1.0 - keep)).sum(0), **g_pos}
+            return {"loss": loss, "grads": grads, "d_enc": (d_feat[:, :E] + d_x).view(B, L, E)}
         tag = self.tagger(enc, sentlens)
         lens, feat, logits = tag["sentlens"], tag["feat"], tag["ner_logits"]
         B, L, E = enc.shape
@@ -444,7 +616,7 @@ class TaskHeads:
         return {"loss": loss, "grads": grads, "d_enc": (d_feat[:, :E] + d_x).view(B, L, E)}
 
     # ---- ... and its backward through upos_clf and upos_hid (what loss.backward() leaves behind pos_forward)
-    def pos_backward(self, enc: torch.Tensor, sentlens, gold_upos, ignore_index=1):
+    def pos_backward(self, enc: torch.Tensor, sentlens, gold_upos, ignore_index=1, masks=None):
         """-> {"loss": fp32 [3] as pos_loss, "grads": {"upos_hid.weight", "upos_hid.bias", "upos_clf.weight",
         "upos_clf.bias"}, "d_enc": the gradient w.r.t. the gathered encoder rows [B,L,E] (zero on padding)}."""
         w = self.w
@@ -452,6 +624,24 @@ class TaskHeads:
         B, L, E = enc.shape
         M = B * L
         x = enc.reshape(M, E).contiguous()
+        if masks is not None:  # model in .train(): masks = {"wd_pos": bool [B,L], "drop_pos": [B,L,Hp]} (:126-129)
+            dev = enc.device
+            m_wd = torch.as_tensor(masks["wd_pos"]).to(device=dev, dtype=torch.bool).reshape(M)
+            m_dp = torch.as_tensor(masks["drop_pos"]).to(dev, torch.float32).reshape(M, -1)
+            xp = TaskHeads._word_drop(x, m_wd, w.repl_pos)
+            hid = ops.linear(xp, w.upos_hid_w, w.upos_hid_b, True, None, 0)
+            hid_d = (hid * m_dp).contiguous()
+            logits = ops.linear(hid_d, w.upos_clf_w, w.upos_clf_b, False, None, 0).view(B, L, -1)
+            gold = torch.as_tensor(gold_upos).to(device=dev, dtype=torch.int32).contiguous()
+            loss = ops.pos_loss(logits, gold, lens, ignore_index)
+            d_logits = ops.pos_loss_grad(logits, gold, lens, loss, ignore_index)
+            U = logits.shape[2]
+            d_hid_d, dWc, dbc = ops.linear_backward(hid_d, w.upos_clf_w, None, d_logits.reshape(M, U).contiguous(), False)
+            d_xp, dWh, dbh = ops.linear_backward(xp, w.upos_hid_w, hid, (d_hid_d * m_dp).contiguous(), True)
+            keep = (~m_wd).reshape(M, 1).to(torch.float32)
+            return {"loss": loss, "d_enc": (d_xp * keep).view(B, L, E),
+                    "grads": {"upos_hid.weight": dWh, "upos_hid.bias": dbh, "upos_clf.weight": dWc, "upos_clf.bias": dbc,
+                              "drop_replacement_pos": (d_xp * (1.0 - keep)).sum(0)}}
         hid = ops.linear(x, w.upos_hid_w, w.upos_hid_b, True, None, 0)            # relu(upos_hid(x))
         logits = ops.linear(hid, w.upos_clf_w, w.upos_clf_b, False, None, 0).view(B, L, -1)
         gold = torch.as_tensor(gold_upos).to(device=enc.device, dtype=torch.int32).contiguous()

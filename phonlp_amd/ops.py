@@ -702,6 +702,20 @@ def biaffine_arc_scores(XF: Tensor, B: int, L: int, Wbt: Tensor, H: int, n_score
     return out
 
 
+def biaffine_arc_scores_raw(XF: Tensor, B: int, L: int, Wbt: Tensor, H: int, n_scorers: int, use_lin: bool,
+                            use_dist: bool) -> Tuple[Tensor, Tensor]:
+    """The same, also returning the raw scorer outputs [3, B, L, L] (what the training loss reads, ref jointmodel/model.py:209-236)."""
+    _need(XF, torch.float32, "XF")
+    dev = XF.device
+    out = torch.empty((B, L, L), dtype=torch.float32, device=dev)
+    raw = torch.zeros((3, B, L, L), dtype=torch.float32, device=dev)
+    nb = lib().phonlp_biaffine_arc_scores_ws_bytes(B, L, H, n_scorers)
+    ws = _ws(nb, dev)
+    check(lib().phonlp_biaffine_arc_scores(_p(XF), B, L, H, n_scorers, int(use_lin), int(use_dist), _p(Wbt), _p(out),
+                                           _p(raw), _p(ws), nb, _stream()), "phonlp_biaffine_arc_scores")
+    return out, raw
+
+
 @torch.library.custom_op("phonlp_amd::label_stage_a_split", mutates_args=())
 def label_stage_a_split(x1p: Tensor, x1_inv: Tensor, wbtp: Tensor, wbt_inv: Tensor, B: int, L: int, H: int,
                         O: int, ones_col: Optional[Tensor] = None) -> Tensor:

@@ -784,6 +784,145 @@ def gen_ner_backward():
     save("ner_backward_small.npz", **arrs)
 
 
+# ---------------------------------------------------------------------------- F9e the three losses in TRAINING mode
+def gen_train_dropout():
+    """dep_forward(eval=False), ner_forward and pos_forward(use_soft_pos=False) of the training model (models/jointmodel/
+    model.py:107-236) in .train() mode -- word dropout with its replacement vectors (models/common/dropout.py:5-27), the
+    nn.Dropout layers on the hidden states and inside the scorers (biaffine.py:82-85) -- with the masks the reference's own
+    modules drew read off their inputs and outputs by forward hooks, then loss.backward(): loss, every parameter's .grad
+    (the replacement vectors' included) and the gradient w.r.t. the gathered encoder rows.  The encoder itself runs in
+    .eval() so that its rows are reproducible.  Masks are stored in the padded [B, L, ...] layout."""
+    import tempfile
+    from torch.nn.utils.rnn import pack_padded_sequence
+    amodel = build_joint_model(seed=1212)
+    from phonlp.models.jointmodel.trainer import JointTrainer
+    from phonlp.models.common.dropout import WordDropout
+    with tempfile.TemporaryDirectory() as td:
+        amodel.phobert.save_pretrained(td)
+        args = dict(amodel.args, pretrained_lm=td)
+        trainer = JointTrainer(args=args, vocab=amodel.vocab, config_phobert=amodel.phobert.config, use_cuda=False)
+    missing, unexpected = trainer.model.load_state_dict(amodel.state_dict(), strict=False)
+    assert not unexpected and all(m.startswith("drop_replacement") for m in missing), (missing, unexpected)
+    model = trainer.model
+    with torch.no_grad():
+        model.crit_ner._transitions.copy_(torch.randn(model.crit_ner._transitions.shape, generator=torch.Generator().manual_seed(6)) * 0.3)
+    model.train()
+    model.phobert.eval()
+    arrs = {f"p_{k}": v.detach().numpy() for k, v in model.state_dict().items() if not k.startswith("phobert.")}
+    arrs["p_dropout"], arrs["p_word_dropout"] = np.float32(args["dropout"]), np.float32(args["word_dropout"])
+    captured = []
+    orig = model.phobert.forward
+
+    def spy(*a, **kw):
+        out = orig(*a, **kw)
+        out[2][-1].retain_grad()
+        captured.append(out)
+        return out
+
+    model.phobert.forward = spy
+    rec = {}
+
+    def word_hook(name):
+        def hook(_m, inp, out):
+            rec.setdefault(name, []).append((out != inp[0]).any(-1).detach().clone())  # the rows that were replaced
+        return hook
+
+    def drop_hook(name, p):
+        def hook(_m, inp, out):
+            # kept entries carry 1/(1-p); where the input is zero the mask cannot be read off and does not matter (the
+            # input is a ReLU output or a padded row: no gradient passes)
+            rec.setdefault(name, []).append(((out != 0).float() / (1.0 - p)).detach().clone())
+        return hook
+
+    for name in ("worddrop_pos", "worddrop_dep", "worddrop_ner"):
+        assert isinstance(getattr(model, name), WordDropout)
+        getattr(model, name).register_forward_hook(word_hook(name))
+    for name in ("drop_pos", "drop_dep"):
+        getattr(model, name).register_forward_hook(drop_hook(name, args["dropout"]))
+    for name in ("unlabeled", "deprel", "linearization", "distance"):
+        getattr(model, name).dropout.register_forward_hook(drop_hook("scorer_" + name, args["dropout"]))
+    with open(os.path.join(REF, "sample_data", "input.txt")) as f:
+        lines = [ln.strip() for ln in f if ln.strip()]
+    g = torch.Generator().manual_seed(15)
+    torch.manual_seed(77)  # the reference's modules draw from the global generator
+    params = dict(model.named_parameters())
+    head_names = [k for k in params if not k.startswith("phobert.")]
+
+    def to_padded(rows, lens):  # PackedSequence-ordered rows [m, ...] -> [B, L, ...] (zeros on padding)
+        B, L = len(lens), max(lens)
+        idx = pack_padded_sequence(torch.arange(B * L).view(B, L), lens, batch_first=True).data
+        out = torch.zeros((B * L,) + tuple(rows.shape[1:]), dtype=rows.dtype)
+        out[idx] = rows
+        return out.view((B, L) + tuple(rows.shape[1:]))
+
+    def finish(tag, c, loss, lens, fsw):
+        last = captured[-1][2][-1]
+        B = len(lens)
+        arrs[f"{tag}{c}_enc"] = torch.stack([last[i].detach().index_select(0, fsw[i]) for i in range(B)]).numpy()
+        arrs[f"{tag}{c}_d_enc"] = torch.stack([last.grad[i].index_select(0, fsw[i]) for i in range(B)]).numpy()
+        arrs[f"{tag}{c}_lens"] = np.asarray(lens, dtype=np.int64)
+        arrs[f"{tag}{c}_loss"] = np.float32(loss.item())
+        for k in head_names:
+            if params[k].grad is not None and bool(params[k].grad.abs().sum() > 0):
+                arrs[f"{tag}{c}_dp_{k}"] = params[k].grad.detach().numpy().copy()
+
+    cases = [lines[10:19] + ["x", "y z w"], lines[33:36]]
+    for c, text in enumerate(cases):
+        sents = [ln.split(" ") for ln in text]
+        # ---- parser
+        data_p = amodel.chunk_batches(amodel.process_data_parser(batch_text=sents), len(sents))
+        tok, fsw, wmask, _, _, lens = amodel.get_batch(0, data_p)
+        B, L = len(lens), max(lens)
+        head = torch.zeros(B, L - 1, dtype=torch.long)
+        rel = torch.zeros(B, L - 1, dtype=torch.long)
+        for b, ln in enumerate(lens):
+            for i in range(1, ln):
+                h = int(torch.randint(0, ln - 1, (1,), generator=g))
+                head[b, i - 1] = h if h < i else h + 1
+                rel[b, i - 1] = int(torch.randint(4, len(amodel.vocab["deprel"]), (1,), generator=g))
+        nwords = int(sum(lens))
+        model.zero_grad()
+        rec.clear()
+        loss, _ = model.dep_forward(tok, fsw, wmask, nwords, lens, head, rel, eval=False)
+        loss.backward()
+        finish("dep", c, loss, lens, fsw)
+        arrs[f"dep{c}_head"], arrs[f"dep{c}_rel"], arrs[f"dep{c}_nwords"] = head.numpy(), rel.numpy(), np.int64(nwords)
+        assert len(rec["worddrop_pos"]) == 1 and len(rec["worddrop_dep"]) == 1 and len(rec["drop_pos"]) == 1 and len(rec["drop_dep"]) == 8
+        arrs[f"dep{c}_m_wd_pos"] = to_padded(rec["worddrop_pos"][0], lens).numpy()
+        arrs[f"dep{c}_m_wd"] = to_padded(rec["worddrop_dep"][0], lens).numpy()
+        arrs[f"dep{c}_m_drop_pos"] = to_padded(rec["drop_pos"][0], lens).numpy()
+        arrs[f"dep{c}_m_hidden"] = torch.stack(rec["drop_dep"]).view(4, 2, B, L, -1).numpy()  # scorer (model.py:185-200 order), W1 / W2 input
+        arrs[f"dep{c}_m_scorer"] = torch.stack([torch.stack(rec["scorer_" + n]) for n in ("unlabeled", "deprel", "linearization", "distance")]).numpy()
+        print(f"train-mode parser case {c}: B={B} L={L} loss={loss.item():.6f} dropped words {int(rec['worddrop_dep'][0].sum())}")
+        # ---- tagger side: NER and POS losses
+        data_t = amodel.chunk_batches(amodel.process_data_tagger(batch_text=sents), len(sents))
+        tok_t, fsw_t, wmask_t, _, _, lens_t = amodel.get_batch(0, data_t)
+        Bt, Lt = len(lens_t), max(lens_t)
+        tags = torch.randint(0, len(amodel.vocab["ner_tag"]), (Bt, Lt), generator=g)
+        model.zero_grad()
+        rec.clear()
+        loss, _ = model.ner_forward(tok_t, fsw_t, wmask_t, lens_t, tags)
+        loss.backward()
+        finish("ner", c, loss, lens_t, fsw_t)
+        arrs[f"ner{c}_tags"] = tags.numpy()
+        arrs[f"ner{c}_m_wd_pos"] = to_padded(rec["worddrop_pos"][0], lens_t).numpy()
+        arrs[f"ner{c}_m_wd"] = to_padded(rec["worddrop_ner"][0], lens_t).numpy()
+        arrs[f"ner{c}_m_drop_pos"] = to_padded(rec["drop_pos"][0], lens_t).numpy()
+        print(f"train-mode ner case {c}: loss={loss.item():.6f}")
+        upos = torch.randint(0, len(amodel.vocab["upos"]), (Bt, Lt), generator=g)
+        model.zero_grad()
+        rec.clear()
+        loss, _ = model.pos_forward(tok_t, fsw_t, lens_t, use_soft_pos=False, upos=upos)
+        loss.backward()
+        finish("pos", c, loss, lens_t, fsw_t)
+        arrs[f"pos{c}_upos"] = upos.numpy()
+        arrs[f"pos{c}_m_wd_pos"] = to_padded(rec["worddrop_pos"][0], lens_t).numpy()
+        arrs[f"pos{c}_m_drop_pos"] = to_padded(rec["drop_pos"][0], lens_t).numpy()
+        print(f"train-mode pos case {c}: loss={loss.item():.6f}")
+    arrs["n_cases"] = np.int64(len(cases))
+    save("train_dropout_small.npz", **arrs)
+
+
 # ---------------------------------------------------------------------------- F10 BASELINE config 1 at full head sizes
 def gen_config1():
     """BASELINE config 1: the reference's annotate() (annotate_model.py:218-339) over all 100 sentences of
@@ -893,6 +1032,9 @@ if __name__ == "__main__":
     if "--only-pos-backward" in sys.argv:
         gen_pos_backward()
         sys.exit(0)
+    if "--only-train-dropout" in sys.argv:
+        gen_train_dropout()
+        sys.exit(0)
     if "--only-biaffine-backward" in sys.argv:
         gen_biaffine_backward()
         sys.exit(0)
@@ -907,6 +1049,7 @@ if __name__ == "__main__":
     gen_trainer()
     gen_dep_loss()
     gen_dep_loss_grad()
+    gen_train_dropout()
     gen_biaffine_backward()
     gen_pos_backward()
     gen_ner_backward()

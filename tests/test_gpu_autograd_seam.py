@@ -107,12 +107,79 @@ def test_update_seam_matches_the_references_losses_and_reaches_the_encoder(golde
     assert got2[0] < got[0], (got, got2)
 
 
-def test_update_seam_refuses_head_dropout(golden):
-    from phonlp_amd.compat import patch_trainer
+def test_update_seam_with_head_dropout(golden):
+    """update() with the heads' dropouts on: masks are drawn per step (compat.draw_masks) -- two calls give different,
+    finite losses, the replacement vectors get gradients, and the share of dropped words / kept units is what p says."""
+    from phonlp_amd.compat import patch_trainer, draw_masks, refresh_heads
     from tests.stub_model import StubJointModel
     z = golden("trainer_small.npz")
     model = StubJointModel(z)
-    model.args.update({"dropout": 0.33, "word_dropout": 0.0})
+    model.args.update({"dropout": 0.33, "word_dropout": 0.2})
+    g = torch.Generator().manual_seed(4)
+    E, D = model._heads["upos_hid.weight"].shape[1], model._heads["dep_hid.weight"].shape[1]
+    model._heads.update({"drop_replacement_pos": torch.randn(E, generator=g) / E ** 0.5,
+                         "drop_replacement_ner": torch.randn(D, generator=g) / D ** 0.5,
+                         "drop_replacement_dep": torch.randn(D, generator=g) / D ** 0.5})
+    for m in model.phobert.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    for v in model._heads.values():
+        if v.is_floating_point():
+            v.requires_grad_(True)
     trainer = patch_trainer(_StubTrainer(model), move_encoder=False, train_seam=True)
-    with pytest.raises(NotImplementedError):
-        trainer.update(None, None, None)
+    T = lambda k: torch.from_numpy(z[k])
+    dep_batch = (T("dep_tokens"), T("dep_first"), T("dep_mask"), T("loss_gold_head"), T("dep_gold_rel"),
+                 int(z["dep_nwords"]), z["dep_oidx"].tolist(), z["dep_lens"].tolist())
+    pos_batch = (T("tag_tokens"), T("tag_first"), T("gold_upos"), z["tag_oidx"].tolist(), z["tag_lens"].tolist())
+    ner_batch = (T("tag_tokens"), T("tag_first"), T("tag_mask"), T("gold_ner"), z["tag_oidx"].tolist(), z["tag_lens"].tolist())
+    a = trainer.update(dep_batch, pos_batch, ner_batch, 0.4, 0.2, 0.4)
+    b = trainer.update(dep_batch, pos_batch, ner_batch, 0.4, 0.2, 0.4)
+    assert all(np.isfinite(a)) and all(np.isfinite(b)) and a != b
+    for k in ("drop_replacement_pos", "drop_replacement_ner", "drop_replacement_dep", "dep_hid.weight"):
+        assert model._heads[k].grad is not None and bool(torch.isfinite(model._heads[k].grad).all())
+    h = refresh_heads(model)
+    lens = [50] * 64
+    mk = draw_masks(h, "parser", 64, 50, lens, 0.33, 0.2, h.w.trans.device, torch.Generator(device=h.w.trans.device).manual_seed(1))
+    assert abs(float(mk["wd"].float().mean()) - 0.2) < 0.03
+    kept = (mk["hidden"]["deprel"][1] > 0).float().mean()
+    assert abs(float(kept) - 0.67) < 0.02 and abs(float(mk["hidden"]["deprel"][1].max()) - 1 / 0.67) < 1e-5
+
+
+@pytest.mark.parametrize("task", ["parser", "ner", "pos"])
+def test_train_mode_with_the_references_dropout_masks(dev, golden, task):
+    """The three losses with the model in .train() (ref jointmodel/model.py:107-236: word dropout + replacement vectors,
+    nn.Dropout on the hidden states and inside the scorers), the masks the reference's own modules drew given as inputs
+    (train_dropout_small.npz: read off those modules by forward hooks): loss, every parameter's .grad -- the replacement
+    vectors' included -- and the encoder rows' gradient equal the reference's."""
+    from phonlp_amd import HeadWeights, TaskHeads, compat
+    z = golden("train_dropout_small.npz")
+    tag = {"parser": "dep", "ner": "ner", "pos": "pos"}[task]
+    order = ("unlabeled", "deprel", "linearization", "distance")  # the order dep_forward calls them in (:185-200)
+    for c in range(int(z["n_cases"])):
+        params = {k[2:]: torch.from_numpy(z[k]).to(dev).requires_grad_(True) for k in z.files
+                  if k.startswith("p_") and z[k].ndim > 0}
+        heads = TaskHeads(HeadWeights.from_state_dict({k: v.detach() for k, v in params.items()}, dev))
+        enc = torch.from_numpy(z[f"{tag}{c}_enc"]).to(dev).requires_grad_(True)
+        lens = z[f"{tag}{c}_lens"].tolist()
+        m = lambda k: torch.from_numpy(z[f"{tag}{c}_m_{k}"])
+        masks = {"wd_pos": m("wd_pos"), "drop_pos": m("drop_pos")}
+        if task == "parser":
+            mh, ms = m("hidden"), m("scorer")
+            masks.update({"wd": m("wd"), "hidden": {n: (mh[i, 0], mh[i, 1]) for i, n in enumerate(order)},
+                          "scorer": {n: (ms[i, 0], ms[i, 1]) for i, n in enumerate(order)}})
+            loss = compat.parser_loss(heads, params, enc, lens, torch.from_numpy(z[f"dep{c}_head"]), torch.from_numpy(z[f"dep{c}_rel"]),
+                                      int(z[f"dep{c}_nwords"]), masks=masks)
+        elif task == "ner":
+            masks["wd"] = m("wd")
+            loss = compat.ner_loss(heads, params, enc, lens, torch.from_numpy(z[f"ner{c}_tags"]), masks=masks)
+        else:
+            loss = compat.pos_loss(heads, params, enc, lens, torch.from_numpy(z[f"pos{c}_upos"]), masks=masks)
+        want = float(z[f"{tag}{c}_loss"])
+        assert abs(float(loss.detach()) - want) <= 1e-4 * abs(want), (float(loss.detach()), want)
+        loss.backward()
+        names = [k[len(f"{tag}{c}_dp_"):] for k in z.files if k.startswith(f"{tag}{c}_dp_")]
+        assert f"drop_replacement_{tag}" in names or task == "pos"
+        assert "drop_replacement_pos" in names
+        for name in names:
+            _check(params[name].grad, z[f"{tag}{c}_dp_{name}"], f"{task} case {c} {name}")
+        _check(enc.grad, z[f"{tag}{c}_d_enc"], f"{task} case {c} d_enc")
