@@ -1030,21 +1030,19 @@ __device__ __forceinline__ void wide_tile_origin(const LinearArgs &a, int t, int
     n0 = (in / gsz) * 256;
 }
 
-// The wide kernel as a PERSISTENT workgroup for the labels-at-heads epilogue (which needs no LDS): one workgroup per
-// CU takes tile after tile of its XCD's chunk of the walk from a counter (a.tile_ctr[8], zeroed by the launch in front:
-// gather_heads_t_kernel), and the operand loads of a tile's first two pairs are issued during the LAST two pairs of the
-// tile before it, so they land behind that tile's epilogue: no workgroup launch and no exposed first-load latency per
-// tile (27 tiles per CU at the headline shape).  The pair pipeline is the one above, continued across tiles (the
-// buffer parity runs on); the last pair of a tile only takes a barrier where the others wait for the next pair and
-// read its fragments -- those registers are the epilogue's -- and the next tile's first fragments are read behind the
-// epilogue.  Needs a.K / 32 >= 4.  No waiting on other workgroups anywhere: a workgroup that draws a number past its
-// chunk leaves.
+// The wide kernel as a PERSISTENT workgroup for the plain dense layers taken transposed (EPI 1: the result as a split
+// image, EPI 2: as fp32 rows; transposed_epilogue above): one workgroup per CU takes every stride-th tile of its XCD's chunk
+// of the walk, and the operand loads of a tile's first two pairs are issued during the LAST two pairs of the tile before
+// it, so they land behind that tile's epilogue: no workgroup launch and no exposed first-load latency per tile.  The pair
+// pipeline is the one above, continued across tiles (the buffer parity runs on); the last pair of a tile only takes a
+// barrier where the others wait for the next pair and read its fragments -- those registers are the epilogue's -- and the
+// next tile's first fragments are read behind the epilogue.  Needs a.K / 32 >= 4.  No waiting on other workgroups.  (The
+// labels-at-heads form of this kernel is linear_f16x3_wide16_heads_kernel below.)
 template <int EPI>
 __global__ __launch_bounds__(512, 1) void linear_f16x3_wide_persist_kernel(LinearArgs a) {
     constexpr int BM = 256, BN = 256, WN = 4, TM = 4, TN = 2;
     constexpr int ROWS = BM + BN, PBUF = ROWS * 128;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    __shared__ int s_next;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -1053,15 +1051,10 @@ __global__ __launch_bounds__(512, 1) void linear_f16x3_wide_persist_kernel(Linea
     const int ntiles = a.num_m * a.num_n, q8 = ntiles >> 3, r8 = ntiles & 7;
     const int chunk0 = xg < r8 ? xg * (q8 + 1) : r8 * (q8 + 1) + (xg - r8) * q8;  // this XCD's tiles: chunk0 .. chunk0 + chunkn
     const int chunkn = q8 + (xg < r8 ? 1 : 0);
-    // EPI 0: tiles drawn from the XCD's counter; EPI 1 / 2 (no counter to zero: these layers are launched from several
-    // streams at once): workgroup jl of the XCD takes tiles jl, jl + stride, ... of the chunk
+    // no counter to zero (these layers are launched from several streams at once): workgroup jl of the XCD takes tiles jl,
+    // jl + stride, ... of the chunk
     const int stride = gridDim.x >> 3;
-    int first = blockIdx.x >> 3;
-    if constexpr (EPI == 0) {
-        if (tid == 0) s_next = atomicAdd(a.tile_ctr + xg, 1);
-        __syncthreads();
-        first = __builtin_amdgcn_readfirstlane(s_next);
-    }
+    const int first = blockIdx.x >> 3;
     if (first >= chunkn) return;
     int cur_tile = first;
     int m0, n0;
@@ -1140,31 +1133,21 @@ __global__ __launch_bounds__(512, 1) void linear_f16x3_wide_persist_kernel(Linea
     // into this pair's buffer between the last eight MFMAs (the barrier is what frees the buffer); 2 = the same if `flag`
     // (wave-uniform: the branches hold nothing but the issue -- two code paths with MFMAs in them made hipcc shuffle the
     // accumulators at the merge and spill a thousand registers); 0 = none.
-    // (EPI 1 / 2: the row operand is the weight image, so the two small terms are taken in the order ah.bl, al.bh -- the
+    // (the row operand is the weight image, so the two small terms are taken in the order ah.bl, al.bh -- the
     // words' low pieces first, as the 256 x 128 kernel does with the words as rows: products commute exactly and k runs the
     // same way, so both kernels give the same bits and a sentence's results do not depend on which of them a batch size picks)
     auto body = [&](int pb, long so, auto join, auto loads, bool flag) {
         constexpr int JOIN = decltype(join)::value, LOADS = decltype(loads)::value;
         const unsigned char *buf = lds + pb * PBUF;
-        if constexpr (EPI == 0) {
-            PHONLP_X3_ROUND(F, al, bh)
-            PHONLP_X3_ROUND(F, ah, bl)
-        } else {
-            PHONLP_X3_ROUND(F, ah, bl)
-            PHONLP_X3_ROUND(F, al, bh)
-        }
+        PHONLP_X3_ROUND(F, ah, bl)
+        PHONLP_X3_ROUND(F, al, bh)
         pin();
         read_frags(buf, 1, G);
         pin();
         PHONLP_X3_ROUND(F, ah, bh)
         pin();
-        if constexpr (EPI == 0) {
-            PHONLP_X3_ROUND(G, al, bh)
-            PHONLP_X3_ROUND(G, ah, bl)
-        } else {
-            PHONLP_X3_ROUND(G, ah, bl)
-            PHONLP_X3_ROUND(G, al, bh)
-        }
+        PHONLP_X3_ROUND(G, ah, bl)
+        PHONLP_X3_ROUND(G, al, bh)
         pin();
         if constexpr (JOIN == 2) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1209,21 +1192,13 @@ __global__ __launch_bounds__(512, 1) void linear_f16x3_wide_persist_kernel(Linea
     for (int q = 0; q < 8; ++q) lds_dma16(src[q] + 128, lds0 + (unsigned)(PBUF + q * 8192));
     int pb = 0;
     for (;;) {
-        int drawn = 0;  // the next tile's number: drawn now, needed npair - 3 pairs from here
-        if constexpr (EPI == 0) {
-            if (tid == 0) drawn = atomicAdd(a.tile_ctr + xg, 1);
-        }
         for (int p = 0; p + 3 < npair; ++p) {
             body(pb, (long)(p + 2) * 128, C2{}, C1{}, true);
             pb ^= 1;
         }
-        if constexpr (EPI == 0) {
-            if (tid == 0) s_next = drawn;
-        }
-        body(pb, (long)(npair - 1) * 128, C2{}, C1{}, true);  // the tile's last loads; its barrier publishes s_next
+        body(pb, (long)(npair - 1) * 128, C2{}, C1{}, true);  // the tile's last loads
         pb ^= 1;
-        int nxt = cur_tile + stride;
-        if constexpr (EPI == 0) nxt = __builtin_amdgcn_readfirstlane(s_next);
+        const int nxt = cur_tile + stride;
         cur_tile = nxt;
         const bool has_next = nxt < chunkn;
         int m1 = m0, n1 = n0;
@@ -1248,8 +1223,7 @@ __global__ __launch_bounds__(512, 1) void linear_f16x3_wide_persist_kernel(Linea
         } else
 #endif
         {
-            if constexpr (EPI == 0) at_heads_epilogue<TM, TN>(acc, a, m0, n0, wm, wn, lane);
-            else transposed_epilogue<TM, TN, EPI == 1>(acc, a, m0, n0, wm, wn, lane, lds, 2u * PBUF + wave * 4096u);
+            transposed_epilogue<TM, TN, EPI == 1>(acc, a, m0, n0, wm, wn, lane, lds, 2u * PBUF + wave * 4096u);
         }
         if (!has_next) break;
         zero_acc();
