@@ -103,7 +103,7 @@ def other_configs(heads, dev, reps):
     from phonlp_amd.profile import KernelTimer
     res = {}
 
-    def run(name, Bc, Lc, ragged=False, pack_pct=None, note=None):
+    def run(name, Bc, Lc, ragged=False, pack_pct=None, note=None, graph=False):
         enc_dep_h, enc_tag_h = S.make_encoder_outputs(Bc, Lc, E, seed=4321 + Bc + Lc)
         lens1 = S.make_sentlens(Bc, Lc, ragged=ragged)  # host lists, as annotate() passes them (ragged batches pack)
         lens = [l - 1 for l in lens1]
@@ -130,15 +130,29 @@ def other_configs(heads, dev, reps):
                      "value": round(Bc / (ms * 1e-3), 1), "unit": "sentences/s",
                      "mst_failures": int((out["mst_status"] != 0).sum()),
                      "kernels_ms": {k: round(v[1], 4) for k, v in sorted(kt.stats.items())}}
+        if graph:  # the same step as one hipGraphLaunch (TaskHeads.capture): what a fixed-shape serving loop pays per batch
+            step = heads.capture(Bc, Lc)
+            step.enc_dep.copy_(ed)
+            step.enc_tag.copy_(et)
+            for _ in range(3):
+                gout = step.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(4 * reps):
+                gout = step.replay()
+            torch.cuda.synchronize()
+            res[name]["graph_replay_ms"] = round((time.perf_counter() - t0) / (4 * reps) * 1e3, 4)
+            res[name]["graph_equals_eager"] = bool(all(torch.equal(gout[k], out[k]) for k in ("pos", "ner", "heads", "rels")))
+            del step
         if note:
             res[name]["note"] = note
 
-    run("config2_B32_L64", 32, 64, note="BASELINE config 2 (launch-latency-bound)")
+    run("config2_B32_L64", 32, 64, note="BASELINE config 2 (launch-latency-bound)", graph=True)
     run("config5_B64_L512", 64, 512, note="BASELINE config 5 (long sentences: round-based MST on the matrix in global "
                                           "memory, unfused label path)")
     run("ragged_B256_L128_packed", B, L, ragged=True, pack_pct=90, note="lengths uniform in [32,128], live words packed")
     run("ragged_B256_L128_padded", B, L, ragged=True, pack_pct=0, note="the same batch at the padded shape")
-    run("latency_B1_L32", 1, 32, note="the reference's default batch_size=1")
+    run("latency_B1_L32", 1, 32, note="the reference's default batch_size=1", graph=True)
     # a corpus walk over 64 DISTINCT batches drawn on the device (streaming form, counts tallied): BASELINE config 4 on one GPU
     corpus = SyntheticCorpus(64 * B, B, L, E, U, O, T, seed=991)
     walk(heads, corpus, 0, 1, dev, last=2)

@@ -198,6 +198,16 @@ int phonlp_arc_kc(int H);
 int phonlp_arc_scores_split(const void *XFp, const float *x_inv, int rows_total, int B, int L, int H, int n_scorers,
                             int use_lin, int use_dist, const void *Wbp, const float *wb_inv, const int32_t *off,
                             const int32_t *sentlens, const void *pad_row, float pad_inv, float *arc_logp, void *stream);
+/* The same with a workspace: for FEW SHORT sentences (3 B <= 512, L <= 128, three scorers) one workgroup per sentence
+ * would run the three scorers in a row on a fraction of the chip; given ws (phonlp_arc_scores_split_ws_bytes(B, L,
+ * n_scorers) bytes, 0 = this shape does not use one; 16-byte aligned) the scorers run as separate workgroups that leave
+ * their raw scores in ws, and a second launch adds the terms in the same order and takes the log-softmax: the same
+ * bits as without ws (tests/test_gpu_small_batch.py), B=32, L=64: 0.113 -> 0.05 ms.  ws = NULL: exactly the entry above. */
+size_t phonlp_arc_scores_split_ws_bytes(int B, int L, int n_scorers);
+int phonlp_arc_scores_split_ws(const void *XFp, const float *x_inv, int rows_total, int B, int L, int H, int n_scorers,
+                               int use_lin, int use_dist, const void *Wbp, const float *wb_inv, const int32_t *off,
+                               const int32_t *sentlens, const void *pad_row, float pad_inv, float *arc_logp, void *ws,
+                               size_t ws_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Label scores -- annotate_model.py:190,215 (deprel DeepBiaffineScorer + .max(3)[1]):

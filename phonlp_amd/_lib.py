@@ -22,6 +22,8 @@ SIGNATURES = {
     "phonlp_linear_split_image": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _p, _f, _f, _i, _p]),
     "phonlp_arc_kc": (_i, [_i]),
     "phonlp_arc_scores_split": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p]),
+    "phonlp_arc_scores_split_ws_bytes": (_z, [_i, _i, _i]),
+    "phonlp_arc_scores_split_ws": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _z, _p]),
     "phonlp_pack_scorer_linear": (_i, [_p, _p, _p, _p, _i, _i, _p, _p, _p]),
     "phonlp_pack_bilinear": (_i, [_p, _i, _i, _p, _p]),
     "phonlp_pos_head_ws_bytes": (_z, [_i, _i, _i, _i, _i, _i]),

@@ -70,6 +70,7 @@ struct ArcSplitArgs {
     const unsigned char *pad;       // packed: image row of a padded head
     float pad_inv;
     long long *dbg;                 // diagnostic builds only (-DARC_STAMPS): cycle stamps of block 0
+    float *raw;                     // PER-SCORER form: [S - 1][B, L, L], the raw scores of scorers 1.. (scorer 0's go to `out`)
 };
 
 #ifdef ARC_STAMPS
@@ -89,6 +90,17 @@ __device__ __forceinline__ float arcs_log1p(float u) {
 }
 __device__ __forceinline__ float arcs_log_sigmoid(float x) { return fminf(x, 0.f) - arcs_log1p(__expf(-fabsf(x))); }
 __device__ __forceinline__ float arcs_softplus(float x) { return x > 20.f ? x : arcs_log1p(__expf(x)); }
+
+// the second and third scorers' terms (annotate_model.py:196-208) of a cell with j - i = d, shared by the fused kernel and
+// the per-scorer form's combine kernel: the same operations in the same order, so both give the same bits
+__device__ __forceinline__ float arc_term_lin(float x, int d) {
+    const float sg = d > 0 ? 1.f : (d < 0 ? -1.f : 0.f);
+    return arcs_log_sigmoid(__fmul_rn(x, sg));
+}
+__device__ __forceinline__ float arc_term_dist(float x, int d) {
+    const float dd = __fsub_rn(fabsf((float)d), __fadd_rn(1.f, arcs_softplus(x)));
+    return -__logf(__fmaf_rn(__fmul_rn(dd, dd), 0.5f, 1.f));
+}
 
 template <int NT>
 struct ArcSplitLayout {
@@ -110,8 +122,12 @@ struct ArcSplitLayout {
 // away, which the register allocation of the headline shape needs); true: up to 512.
 // SKIP (short sentences, L <= 96: a variant of its own, so that the headline shape keeps its register allocation): the waves of
 // row tiles and head columns beyond the sentence do not compute.
-template <int NT, bool LONG, bool SKIP = false>
+// PER_SCORER (few short sentences: fewer workgroups than a third of the CUs would otherwise run three scorers in a row): a workgroup
+// per (sentence, scorer), blockIdx.y = the scorer; the raw scores go to `out` (scorer 0) / `raw` (the others) and
+// arc_combine_kernel adds the terms in the fused form's order and takes the log-softmax.
+template <int NT, bool LONG, bool SKIP = false, bool PER_SCORER = false>
 __global__ __launch_bounds__(512, 1) void arc_f16x3_kernel(ArcSplitArgs a) {
+    static_assert(!(LONG && PER_SCORER), "the per-scorer form is for sentences of up to 128 words");
     using Ly = ArcSplitLayout<NT>;
     constexpr int KC = Ly::KC, NTW = Ly::NTW, NLW = Ly::NLW, STAGE_A = Ly::STAGE_A, SLAB_B = Ly::SLAB_B;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -151,8 +167,9 @@ __global__ __launch_bounds__(512, 1) void arc_f16x3_kernel(ArcSplitArgs a) {
     float *obase = a.out + ((long)b * L + i0 + 32 * mt) * L;
 
     ARC_STAMP(0);
+    const int s_first = PER_SCORER ? blockIdx.y : 0, s_end = PER_SCORER ? blockIdx.y + 1 : a.S;
 #pragma unroll 1
-    for (int s = 0; s < a.S; ++s) {
+    for (int s = s_first; s < s_end; ++s) {
         // ------------------------------------------------------------------------------------------ phase A
         const unsigned char *srcA[NLW];
 #pragma unroll
@@ -397,10 +414,17 @@ __global__ __launch_bounds__(512, 1) void arc_f16x3_kernel(ArcSplitArgs a) {
         // cell (k, e): row 4 hh + (e & 3) + 8 (e >> 2) of the row tile, column 32 k of the wave's pair; one loop per scorer, the
         // scorer switch outside it
         auto cell_ok = [&](int k, int e) {
-            return jbase + 32 * (2 * nh + k) + r < L && i0 + 32 * mt + acc_row(e, lane) < L;
+            return jbase + 32 * (2 * nh + k) + r < L && i0 + 32 * mt + acc_row(e, lane) < len;  // (padded dependents' rows stay untouched)
         };
         if (idle) {
             // nothing of this wave's cells is inside the sentence
+        } else if (PER_SCORER) {
+            float *rb = s == 0 ? ob : a.raw + (long)(s - 1) * a.B * L * L + (ob - a.out);
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if (cell_ok(k, e)) rb[(long)((e & 3) + 8 * (e >> 2)) * L + 32 * k] = acc2[k][e] * fi[e] * gj[k];
         } else if (s == 0) {
 #pragma unroll
             for (int k = 0; k < 2; ++k)
@@ -420,8 +444,7 @@ __global__ __launch_bounds__(512, 1) void arc_f16x3_kernel(ArcSplitArgs a) {
                     for (int e = 0; e < 16; ++e) {
                         const int d = dj + 32 * k - ((e & 3) + 8 * (e >> 2));
                         const float x = acc2[k][e] * fi[e] * gj[k];
-                        const float sg = d > 0 ? 1.f : (d < 0 ? -1.f : 0.f);
-                        prev[k][e] += arcs_log_sigmoid(x * sg);
+                        prev[k][e] = __fadd_rn(prev[k][e], arc_term_lin(x, d));
                     }
             } else {
 #pragma unroll
@@ -430,8 +453,7 @@ __global__ __launch_bounds__(512, 1) void arc_f16x3_kernel(ArcSplitArgs a) {
                     for (int e = 0; e < 16; ++e) {
                         const int d = dj + 32 * k - ((e & 3) + 8 * (e >> 2));
                         const float x = acc2[k][e] * fi[e] * gj[k];
-                        const float dd = fabsf((float)d) - (1.f + arcs_softplus(x));
-                        prev[k][e] += -__logf(dd * dd / 2.f + 1.f);
+                        prev[k][e] = __fadd_rn(prev[k][e], arc_term_dist(x, d));
                     }
             }
 #pragma unroll
@@ -446,6 +468,7 @@ __global__ __launch_bounds__(512, 1) void arc_f16x3_kernel(ArcSplitArgs a) {
     // ---------------------------------------------------------------------------------------------- log-softmax, store
     // over ALL L head columns, padding included (:214), diagonal -inf (:210-211): a wavefront per row, sixteen rows each,
     // on the sums the block's wavefronts left in the output rows
+    if constexpr (PER_SCORER) return;  // arc_combine_kernel finishes the rows
     __syncthreads();
     if constexpr (!LONG) {
         // sixteen rows per wavefront, FOUR LANES PER ROW (lane = 4 row + quarter): a lane reduces its 32 columns in its own
@@ -540,6 +563,75 @@ __global__ __launch_bounds__(512, 1) void arc_f16x3_kernel(ArcSplitArgs a) {
     ARC_STAMP(13);
 }
 
+// Per-scorer form, second launch: out[b][i][j] = log-softmax_j(raw0 + term_lin(raw1) + term_dist(raw2)) -- the fused
+// kernel's sums, operation by operation -- sixteen rows per wavefront, four lanes per row as above.  L <= 128.
+__global__ __launch_bounds__(512) void arc_combine_kernel(ArcSplitArgs a) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, L = a.L;
+    const int len = a.off ? min(max(a.sentlens[b], 0), L) : L;
+    const int i = 16 * wave + (lane >> 2), q4 = lane & 3;
+    if (i >= len) return;
+    float *orow = a.out + ((long)b * L + i) * L + 32 * q4;
+    const float *r1 = a.raw + (orow - a.out), *r2 = r1 + (long)a.B * L * L;
+    const bool lin = a.S == 3 && a.use_lin, dist = a.S == 3 && a.use_dist;
+    float v[32];
+    if ((L & 3) == 0) {  // 16-byte aligned rows: all of a lane's loads in flight together
+        float4 t0[8], t1[8], t2[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const bool in = 32 * q4 + 4 * c < L;
+            t0[c] = in ? *reinterpret_cast<const float4 *>(orow + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            t1[c] = in && lin ? *reinterpret_cast<const float4 *>(r1 + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            t2[c] = in && dist ? *reinterpret_cast<const float4 *>(r2 + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {
+            const int j = 32 * q4 + c;
+            const float x0 = reinterpret_cast<const float *>(&t0[c >> 2])[c & 3];
+            const float x1 = reinterpret_cast<const float *>(&t1[c >> 2])[c & 3];
+            const float x2 = reinterpret_cast<const float *>(&t2[c >> 2])[c & 3];
+            float t = x0;
+            if (lin) t = __fadd_rn(t, arc_term_lin(x1, j - i));
+            if (dist) t = __fadd_rn(t, arc_term_dist(x2, j - i));
+            v[c] = (j < L && j != i) ? t : -INFINITY;
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {
+            const int j = 32 * q4 + c;
+            float t = -INFINITY;
+            if (j < L) {
+                t = orow[c];
+                if (lin) t = __fadd_rn(t, arc_term_lin(r1[c], j - i));
+                if (dist) t = __fadd_rn(t, arc_term_dist(r2[c], j - i));
+            }
+            v[c] = j == i ? -INFINITY : t;
+        }
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) m = fmaxf(m, v[c]);
+    m = fmaxf(m, __shfl_xor(m, 1));
+    m = fmaxf(m, __shfl_xor(m, 2));
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) sum += __expf(v[c] - m);
+    sum += __shfl_xor(sum, 1);
+    sum += __shfl_xor(sum, 2);
+    const float ls = __logf(sum);
+    if ((L & 3) == 0) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            if (32 * q4 + 4 * c < L)
+                *reinterpret_cast<float4 *>(orow + 4 * c) = make_float4((v[4 * c] - m) - ls, (v[4 * c + 1] - m) - ls,
+                                                                         (v[4 * c + 2] - m) - ls, (v[4 * c + 3] - m) - ls);
+    } else {
+#pragma unroll
+        for (int c = 0; c < 32; ++c)
+            if (32 * q4 + c < L) orow[c] = (v[c] - m) - ls;
+    }
+}
+
 int arc_split_kc(int H) {  // columns per image segment: the smallest supported multiple of 32 that holds H + 1 features
     const int need = H + 1;
     const int opts[] = {64, 128, 256, 416};
@@ -558,11 +650,25 @@ static int launch_arc_split(const ArcSplitArgs &a, hipStream_t stream) {
             hipFuncSetAttribute((const void *)arc_f16x3_kernel<NT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 ArcSplitLayout<NT>::TOTAL) != hipSuccess ||
             hipFuncSetAttribute((const void *)arc_f16x3_kernel<NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                ArcSplitLayout<NT>::TOTAL) != hipSuccess ||
+            hipFuncSetAttribute((const void *)arc_f16x3_kernel<NT, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                ArcSplitLayout<NT>::TOTAL) != hipSuccess ||
+            hipFuncSetAttribute((const void *)arc_f16x3_kernel<NT, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 ArcSplitLayout<NT>::TOTAL) != hipSuccess)
             return fail(PHONLP_ERR_LAUNCH, "arc_scores_split: cannot raise the dynamic LDS limit");
         once.mark(dev);
     }
     ProfScope ps("arc_fused", stream);
+    if (a.raw) {  // the per-scorer form (arc_per_scorer() said so and the caller brought the buffer)
+        if (a.L <= 96)
+            hipLaunchKernelGGL((arc_f16x3_kernel<NT, false, true, true>), dim3(a.B, a.S), dim3(512), ArcSplitLayout<NT>::TOTAL, stream, a);
+        else
+            hipLaunchKernelGGL((arc_f16x3_kernel<NT, false, false, true>), dim3(a.B, a.S), dim3(512), ArcSplitLayout<NT>::TOTAL, stream, a);
+        const int rc = check_launch("arc_f16x3_kernel");
+        if (rc) return rc;
+        hipLaunchKernelGGL(arc_combine_kernel, dim3(a.B), dim3(512), 0, stream, a);
+        return check_launch("arc_combine_kernel");
+    }
     if (a.L <= 96) hipLaunchKernelGGL((arc_f16x3_kernel<NT, false, true>), dim3(a.B), dim3(512), ArcSplitLayout<NT>::TOTAL, stream, a);
     else if (a.L <= 128) hipLaunchKernelGGL((arc_f16x3_kernel<NT, false>), dim3(a.B), dim3(512), ArcSplitLayout<NT>::TOTAL, stream, a);
     else hipLaunchKernelGGL((arc_f16x3_kernel<NT, true>), dim3(a.B, (a.L + 127) / 128), dim3(512), ArcSplitLayout<NT>::TOTAL, stream, a);
@@ -575,10 +681,26 @@ using namespace phonlp;
 
 extern "C" int phonlp_arc_kc(int H) { return H > 0 ? arc_split_kc(H) : 0; }
 
+// the per-scorer form pays when three scorers in a row would run on fewer than a third of the CUs' worth of workgroups twice over
+static bool arc_per_scorer(int B, int L, int n_scorers) { return n_scorers == 3 && L <= 128 && 3L * B <= 512; }
+
+extern "C" size_t phonlp_arc_scores_split_ws_bytes(int B, int L, int n_scorers) {
+    if (B <= 0 || L <= 0 || !arc_per_scorer(B, L, n_scorers)) return 0;
+    return (size_t)(n_scorers - 1) * B * L * L * sizeof(float);
+}
+
 extern "C" int phonlp_arc_scores_split(const void *XFp, const float *x_inv, int rows_total, int B, int L, int H,
                                        int n_scorers, int use_lin, int use_dist, const void *Wbp, const float *wb_inv,
                                        const int32_t *off, const int32_t *sentlens, const void *pad_row, float pad_inv,
                                        float *arc_logp, void *stream) {
+    return phonlp_arc_scores_split_ws(XFp, x_inv, rows_total, B, L, H, n_scorers, use_lin, use_dist, Wbp, wb_inv, off, sentlens,
+                                      pad_row, pad_inv, arc_logp, nullptr, 0, stream);
+}
+
+extern "C" int phonlp_arc_scores_split_ws(const void *XFp, const float *x_inv, int rows_total, int B, int L, int H,
+                                          int n_scorers, int use_lin, int use_dist, const void *Wbp, const float *wb_inv,
+                                          const int32_t *off, const int32_t *sentlens, const void *pad_row, float pad_inv,
+                                          float *arc_logp, void *ws, size_t ws_bytes, void *stream) {
     const int KC = H > 0 ? arc_split_kc(H) : 0;
     if (!XFp || !x_inv || !Wbp || !wb_inv || !arc_logp || B <= 0 || L <= 0 || rows_total <= 0 ||
         (n_scorers != 1 && n_scorers != 3))
@@ -594,6 +716,12 @@ extern "C" int phonlp_arc_scores_split(const void *XFp, const float *x_inv, int 
     a.B = B; a.L = L; a.S = n_scorers; a.rows_total = rows_total;
     a.use_lin = use_lin; a.use_dist = use_dist;
     a.off = off; a.sentlens = sentlens; a.pad = (const unsigned char *)pad_row; a.pad_inv = pad_inv;
+    if (ws) {
+        const size_t need = phonlp_arc_scores_split_ws_bytes(B, L, n_scorers);
+        if (need && (ws_bytes < need || ((uintptr_t)ws & 15)))
+            return fail(PHONLP_ERR_SHAPE, "arc_scores_split_ws: workspace too small (phonlp_arc_scores_split_ws_bytes) or unaligned");
+        if (need) a.raw = (float *)ws;
+    }
 #ifdef ARC_STAMPS
     a.dbg = getenv("PHONLP_ARC_DBG") ? (long long *)strtoull(getenv("PHONLP_ARC_DBG"), nullptr, 0) : nullptr;
 #endif

@@ -811,6 +811,76 @@ __global__ __launch_bounds__(256, 2) void linear_f16x3_dma_kernel(LinearArgs a) 
     linear_epilogue<TM, TN, WM, WN>(acc, reinterpret_cast<float *>(lds), a, m0, n0, wm, wn, lane, wave);
 }
 
+// The SMALL form, for launches of a few hundred 64 x 64 tiles at most (B = 1 ... 32 sentences): such a product is a
+// LATENCY chain, not a bandwidth or MFMA problem -- the 256 x 128 kernel above keeps two k16 stages in flight per
+// workgroup and, with a handful of workgroups on the chip, every stage waits most of a memory round trip (B = 1, L = 32,
+// K = 768: 48 stages in 36 us).  Here: 64 x 64 block tile (four waves of 32 x 32, one accumulator tile each: four to eight
+// times as many workgroups pull the operands), k16 stages of 8 KB in a ring of SIXTEEN (fifteen in flight: 120 KB per
+// workgroup, one workgroup per CU), the same LDS image, DMA pattern and MFMA order (al.bh, ah.bl, ah.bh per stage) as
+// above, hence the same bits.  The loop is branch-free: the loads of the stages beyond K re-fetch the last stage into
+// buffers nobody reads again, so one s_waitcnt immediate serves every iteration.
+template <int TAG, int NBUF>
+__global__ __launch_bounds__(256, 1) void linear_f16x3_small_kernel(LinearArgs a) {
+    constexpr int BM = 64, BN = 64, WM = 2, WN = 2, TM = 1, TN = 1;
+    constexpr int ROWS = BM + BN, BUF = ROWS * 64;
+    static_assert(WM * WN * 32 * (TN * 32 + 4) * 4 <= NBUF * BUF, "epilogue patch must fit");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int nst = a.K >> 4;
+    const int m0 = (blockIdx.x % a.num_m) * BM, n0 = (blockIdx.x / a.num_m) * BN;
+    // wave-load u = 4q + wave (q = 0, 1) fills rows 16u .. 16u+15 of the stage image (A rows 0-63, B rows 64-127)
+    const int lr = lane >> 2, chunk = (lane & 3) ^ ((lane >> 4) & 3);
+    const unsigned char *src[2];
+    {
+        int row = m0 + 16 * wave + lr;
+        row = row < a.M ? row : a.M - 1;
+        src[0] = reinterpret_cast<const unsigned char *>(a.X) + (long)row * a.ldx + chunk * 16;
+        row = n0 + 16 * wave + lr;
+        row = row < a.N ? row : a.N - 1;
+        src[1] = reinterpret_cast<const unsigned char *>(a.W) + (long)row * a.ldw + chunk * 16;
+    }
+    const unsigned lds0 = (unsigned)(uintptr_t)lds + (unsigned)__builtin_amdgcn_readfirstlane(wave) * 1024u;
+    auto issue_stage = [&](int st, int buf) {
+        const long so = (long)(st < nst ? st : nst - 1) * 64;
+        lds_dma16(src[0] + so, lds0 + (unsigned)(buf * BUF));
+        lds_dma16(src[1] + so, lds0 + (unsigned)(buf * BUF + 4096));
+    };
+    const int r = lane & 31, hh = lane >> 5;
+    const int sw = (r >> 2) & 3;
+    const int off_h = ((2 * hh) ^ sw) << 4, off_l = ((2 * hh + 1) ^ sw) << 4;
+    const int a_ofs = (wm * 32 + r) * 64;
+    const int b_ofs = (BM + wn * 32 + r) * 64;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[0][0][e] = 0.f;
+
+#pragma unroll
+    for (int s = 0; s < NBUF - 1; ++s) issue_stage(s, s);
+    int cur = 0;
+    for (int s = 0; s < nst; ++s) {
+        // stage s has landed (the 14 stages behind it may be in flight); behind the barrier every wave's pieces of it
+        // have, and every wave is through reading stage s-1, whose buffer takes stage s+15
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NBUF - 2)) : "memory");
+        lds_barrier();
+        issue_stage(s + NBUF - 1, cur == 0 ? NBUF - 1 : cur - 1);
+        const unsigned char *buf = lds + cur * BUF;
+        const u32x4 bh = *reinterpret_cast<const u32x4 *>(buf + b_ofs + off_h);
+        const u32x4 al = *reinterpret_cast<const u32x4 *>(buf + a_ofs + off_l);
+        const u32x4 bl = *reinterpret_cast<const u32x4 *>(buf + b_ofs + off_l);
+        const u32x4 ah = *reinterpret_cast<const u32x4 *>(buf + a_ofs + off_h);
+        acc[0][0] = PHONLP_F16_MFMA(al, bh, acc[0][0]);  // smallest terms first, as everywhere
+        acc[0][0] = PHONLP_F16_MFMA(ah, bl, acc[0][0]);
+        acc[0][0] = PHONLP_F16_MFMA(ah, bh, acc[0][0]);
+        cur = cur == NBUF - 1 ? 0 : cur + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the surplus loads land before the epilogue's patch reuses the ring
+    lds_barrier();
+    linear_epilogue<TM, TN, WM, WN>(acc, reinterpret_cast<float *>(lds), a, m0, n0, wm, wn, lane, wave);
+}
+
 // The WIDE form: 256 x 256 block tile, EIGHT waves of 128 x 64, one workgroup per CU (two waves per SIMD as above), and
 // the operands fetched a k32 PAIR of stages at a time, 128 contiguous bytes per row.
 //
@@ -1590,6 +1660,33 @@ int launch_linear_f16x3(const char *tag, const void *Xp, long pitch_x, const flo
         (void)hipGetDevice(&cur_dev);
         return n_cu[cur_dev & 63] & ~7;
     };
+    // few tiles: the small form (64 x 64 tiles; a ring of 16 stages with one workgroup per CU while every tile has a CU of its
+    // own, of 8 with two per CU beyond)
+    {
+        static const int small_max = getenv("PHONLP_SMALL_MAX_TILES") ? atoi(getenv("PHONLP_SMALL_MAX_TILES")) : 1280;
+        const long nsmall = (long)ceil_div(M, 64) * ceil_div(N, 64);
+        if (!rows4 && !at_heads && nsmall <= small_max) {
+            constexpr int STAGE_SMALL = 128 * 64;
+            static PerDeviceOnce small_once;
+            int sdev;
+            if (small_once.pending(&sdev)) {
+                if (hipFuncSetAttribute((const void *)linear_f16x3_small_kernel<0, 16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        16 * STAGE_SMALL) != hipSuccess ||
+                    hipFuncSetAttribute((const void *)linear_f16x3_small_kernel<0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        8 * STAGE_SMALL) != hipSuccess)
+                    return fail(PHONLP_ERR_LAUNCH, "linear_split: cannot raise the dynamic LDS limit");
+                small_once.mark(sdev);
+            }
+            a.num_m = ceil_div(M, 64);
+            a.num_n = ceil_div(N, 64);
+            ProfScope pss(tag, stream);
+            if (nsmall <= 256)
+                hipLaunchKernelGGL((linear_f16x3_small_kernel<0, 16>), dim3((unsigned)nsmall), dim3(256), 16 * STAGE_SMALL, stream, a);
+            else
+                hipLaunchKernelGGL((linear_f16x3_small_kernel<0, 8>), dim3((unsigned)nsmall), dim3(256), 8 * STAGE_SMALL, stream, a);
+            return check_launch("linear_f16x3_small_kernel");
+        }
+    }
     // The plain layers at large sizes (W1/W2 of the scorers, upos_hid) on the persistent wide kernel, taken TRANSPOSED (row
     // operand = the weight image, column operand = the words): the accumulator lane then holds four consecutive features of
     // ONE word, so the epilogue stores 16-byte (fp32 rows) or 8-byte (split image) pieces straight from the registers -- the

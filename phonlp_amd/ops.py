@@ -668,7 +668,7 @@ def arc_scores_split(xfp: Tensor, xf_inv: Tensor, B: int, L: int, H: int, n_scor
                      pad_row: Optional[Tensor], pad_inv: float) -> Tensor:
     """Engine 2: stages A and B of the arc scorers fused, from the first-layer IMAGE (linear_split_image) -> arc
     log-probs [B,L,L].  Packed rows: off / sentlens / pad_row (image row) / pad_inv; padded dependents' rows are NOT
-    written.  include/phonlp_heads.h phonlp_arc_scores_split."""
+    written.  include/phonlp_heads.h phonlp_arc_scores_split_ws (the workspace form: per-scorer workgroups at small B)."""
     _need(xfp, torch.uint8, "xfp")
     _need(wbp, torch.uint8, "wbp")
     _need(xf_inv, torch.float32, "xf_inv")
@@ -677,9 +677,11 @@ def arc_scores_split(xfp: Tensor, xf_inv: Tensor, B: int, L: int, H: int, n_scor
     if KC == 0 or xfp.shape[1] != n_scorers * 2 * KC * 4 or tuple(wbp.shape) != (n_scorers * KC, KC * 4):
         raise ValueError("arc_scores_split: images do not match H / n_scorers")
     out = torch.empty((B, L, L), dtype=torch.float32, device=xfp.device)
-    check(lib().phonlp_arc_scores_split(_p(xfp), _p(xf_inv), xfp.shape[0], B, L, H, n_scorers, int(use_lin), int(use_dist),
-                                        _p(wbp), _p(wb_inv), _p(off), _p(sentlens), _p(pad_row), float(pad_inv), _p(out),
-                                        _stream()), "phonlp_arc_scores_split")
+    nb = int(lib().phonlp_arc_scores_split_ws_bytes(B, L, n_scorers))  # > 0: few short sentences, a workgroup per scorer
+    ws = _ws(nb, xfp.device) if nb else None
+    check(lib().phonlp_arc_scores_split_ws(_p(xfp), _p(xf_inv), xfp.shape[0], B, L, H, n_scorers, int(use_lin),
+                                           int(use_dist), _p(wbp), _p(wb_inv), _p(off), _p(sentlens), _p(pad_row),
+                                           float(pad_inv), _p(out), _p(ws), nb, _stream()), "phonlp_arc_scores_split_ws")
     return out
 
 

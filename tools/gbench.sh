@@ -9,5 +9,5 @@ d = json.load(open("gpurun_out/r3/$N.json"))
 print("step", round(d["ms_per_step"], 4), "stageA", round(d["roofline"]["mean_ms"], 4), "frac", round(d["roofline"]["frac"], 4),
       "streaming", round(d.get("streaming", {}).get("ms_per_step", 0), 4), "graph", round(d.get("graph_replay", {}).get("ms_per_step", 0), 4))
 print(d["kernels_ms"])
-for k, v in d.get("other_configs", {}).items(): print(k, v["ms_per_step"], v.get("kernels_ms", ""))
+for k, v in d.get("other_configs", {}).items(): print(k, v["ms_per_step"], v.get("graph_replay_ms", ""), v.get("graph_equals_eager", ""), v.get("kernels_ms", ""))
 PY
