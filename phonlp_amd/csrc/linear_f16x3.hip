@@ -1356,6 +1356,14 @@ __device__ __forceinline__ void at_heads_epilogue16(f32x4v (&acc)[8][4], const L
         const bool tv = tile_row < a.M;
         if (blk != cur_blk) {  // wave-uniform: the wave's four relations nearly always share one block of 32 head features
             cur_blk = blk;
+#ifdef PHONLP_ABLATION
+            if (a.dbg == 5) {  // timing only: no loads of the heads' features (is their latency exposed?)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) x[j][hf] = make_float4(cs[j], cs[j], 1.f, 2.f);
+            } else
+#endif
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
                 const int d2 = blk * 32 + 16 * hf + 4 * q;
