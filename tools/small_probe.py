@@ -1,5 +1,6 @@
-"""Times the first layers of the heads at small shapes and prints a checksum of their outputs' bits (run under
-PHONLP_SMALL_MAX_TILES=0 and without: same checksums = the small kernel gives the 256 x 128 kernel's bits).
+"""Times the first layers of the heads at small shapes and prints a checksum of their outputs' bits (two builds of the library
+with different `small_max` in launch_linear_f16x3 must print the same checksums: the small kernel gives the 256 x 128
+kernel's bits; tests/test_gpu_small_batch.py holds that property in the suite).
 python tools/small_probe.py "B,L B,L ..." """
 import os, sys, hashlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -31,4 +32,4 @@ for B, L in shapes:
         ys = y if isinstance(y, (tuple, list)) else (y,)
         h = hashlib.md5(b"".join(t.contiguous().view(torch.uint8).cpu().numpy().tobytes() for t in ys)).hexdigest()[:10]
         out.append(f"{name}: {st[0][1]*1e3:.1f} us (min {st[0][2]*1e3:.1f}) {h}")
-    print(f"B={B} L={L} M={M} SMALL_MAX={os.environ.get('PHONLP_SMALL_MAX_TILES','-')}", " | ".join(out), flush=True)
+    print(f"B={B} L={L} M={M}", " | ".join(out), flush=True)
