@@ -3,6 +3,9 @@ round-based decode hands to the reference-order kernels (and why).  usage: pytho
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+if os.environ.get("PHONLP_LIB"):  # A/B of two builds of the library on one box
+    from phonlp_amd import _lib
+    _lib.LIB_PATH = os.path.abspath(os.environ["PHONLP_LIB"])
 from phonlp_amd import HeadWeights, TaskHeads, ops, synthetic as S
 B, L = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (64, 512)
 nb = int(sys.argv[3]) if len(sys.argv) > 3 else 6
