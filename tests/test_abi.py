@@ -115,6 +115,14 @@ def test_argument_errors_without_gpu(heads_lib):
     assert heads_lib.phonlp_softmax_rows_backward(one, None, 4, 24, one, None) == -1
     assert heads_lib.phonlp_crf_nll_grad_static_max_bytes() == 4 << 20
     assert heads_lib.phonlp_crf_nll_grad_static(one, one, None, None, one, 4096, 4, 64, 1.0, one, one, None) == -4  # B*T*T*4 > 4 MiB
+    # the arc scorers' per-scorer form: a workspace only for few short sentences; bad arguments and a short workspace are refused
+    assert heads_lib.phonlp_arc_scores_split_ws_bytes(32, 64, 3) == 2 * 32 * 64 * 64 * 4
+    assert heads_lib.phonlp_arc_scores_split_ws_bytes(1, 32, 3) == 2 * 32 * 32 * 4
+    assert heads_lib.phonlp_arc_scores_split_ws_bytes(200, 64, 3) == 0  # 3 B > 512: a workgroup per sentence
+    assert heads_lib.phonlp_arc_scores_split_ws_bytes(8, 200, 3) == 0 and heads_lib.phonlp_arc_scores_split_ws_bytes(8, 64, 1) == 0
+    assert heads_lib.phonlp_arc_scores_split_ws(None, one, 64, 1, 64, 400, 3, 1, 1, one, one, None, None, None, 0.0, one, None, 0, None) == -1
+    assert heads_lib.phonlp_arc_scores_split_ws(one, one, 64, 1, 64, 400, 3, 1, 1, one, one, None, None, None, 0.0, one, one, 16, None) == -1
+    assert b"workspace" in heads_lib.phonlp_last_error()
     assert heads_lib.phonlp_get_mst_fast_path() in (0, 1)
     assert heads_lib.phonlp_mst_fallback_counter_offset(256, 128) > 0 and heads_lib.phonlp_mst_fallback_counter_offset(64, 512) > 0
     assert heads_lib.phonlp_mst_fallback_counter_offset(8, 136) == -1  # the reference-order kernel alone decodes this length
