@@ -106,3 +106,34 @@ def test_arc_workspace_form_matches_plain_entry(dev):
     rc = lib().phonlp_arc_scores_split_ws(_p(xfp), _p(xfi), xfp.shape[0], B, L, w.H, 3, 1, 1, _p(w.arc_Wbq_s[0]), _p(w.arc_Wbq_s[1]),
                                           None, None, None, 0.0, _p(out), _p(ws), 16, _stream())
     assert rc != 0
+
+
+@pytest.mark.parametrize("N,K", [(17, 100), (401, 800), (808, 48), (64, 16), (130, 1000)])
+def test_dense_layer_rows_do_not_depend_on_the_batch(dev, N, K):
+    """Engine-2 dense layer (phonlp_linear_split): the rows of a product over a few words (64 x 64 tiles, deep ring) carry the bits
+    of the same rows inside a product over many (256 x 128 / transposed 256 x 256 tiles), for odd N and K, with bias + ReLU, a
+    padding mask and its pad value."""
+    from phonlp_amd import ops
+    big_m = 100352 if N < 100 else 40960  # > 1280 tiles of 64 x 64: the large kernels
+    L = 64
+    g = torch.Generator(device=dev); g.manual_seed(N * 1000 + K)
+    K4 = (K + 3) // 4 * 4
+    X = torch.randn(big_m, K4, device=dev, generator=g) * torch.rand(big_m, 1, device=dev, generator=g) * 4
+    W = torch.randn(N, K4, device=dev, generator=g)
+    if K4 != K:
+        X[:, K:] = 0
+        W[:, K:] = 0
+    bias = torch.randn(N, device=dev, generator=g)
+    padv = torch.randn(N, device=dev, generator=g)
+    xp, xi = ops.split_rows(X)
+    wp, wi = ops.split_rows(W)
+    lens_big = torch.randint(1, L + 1, (big_m // L,), device=dev, generator=g).to(torch.int32)
+    for relu, masked in ((True, False), (False, True), (True, True)):
+        sl = lens_big if masked else None
+        y_big = ops.linear_split(xp, xi, wp, wi, bias, K4, relu, sl, L if masked else 0, padv if masked else None, 0)
+        for m in (1, 5, 63, 64, 65, 200, 1024):
+            rows = (m + L - 1) // L * L if masked else m  # whole sentences under a mask
+            y = ops.linear_split(xp[:rows].contiguous(), xi[:rows].contiguous(), wp, wi, bias, K4, relu,
+                                 lens_big[:rows // L].contiguous() if masked else None, L if masked else 0,
+                                 padv if masked else None, 0)
+            assert torch.equal(y.view(torch.int32), y_big[:rows].view(torch.int32)), (N, K, relu, masked, m)
