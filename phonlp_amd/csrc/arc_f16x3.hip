@@ -37,19 +37,6 @@ namespace phonlp {
 typedef _Float16 af16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 af16x4 __attribute__((ext_vector_type(4)));
 
-#ifndef ARC_PIN_MODE
-#define ARC_PIN_MODE 0
-#endif
-#ifndef ARC_NBUF
-#define ARC_NBUF 4
-#endif
-#if ARC_PIN_MODE == 1
-#define ARC_PIN(X) asm volatile("" : "+v"(X))
-#elif ARC_PIN_MODE == 2
-#define ARC_PIN(X) asm volatile("" : "+a"(X))
-#else
-#define ARC_PIN(X) do {} while (0)
-#endif
 #define ARC_MFMA(A, B, C) \
     __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(af16x8, A), __builtin_bit_cast(af16x8, B), C, 0, 0, 0)
 
@@ -111,7 +98,6 @@ struct ArcSplitLayout {
     static constexpr int NLW = (NLA + 7) / 8;       // per wavefront (the last ones may be dummies)
     static constexpr int STAGE_A = NLW * 8 * 1024;
     static constexpr int SLAB_B = 2 * 128 * 64;     // phase B: a k32 chunk of the heads' X2, two k16 stages of 128 rows
-    static_assert(true, "");
     static constexpr int NSLAB = 5;                 // phase B: slabs in the ring (NSLAB - 1 in flight: they come from HBM / MALL)
     static constexpr int RING_A = 3 * STAGE_A, RING_B = NSLAB * SLAB_B + 4 * 2 * 4096;  // B: the slabs + two patches per row tile
     static constexpr int RING = RING_A > RING_B ? RING_A : RING_B;
@@ -238,8 +224,6 @@ __global__ __launch_bounds__(512, 1) void arc_f16x3_kernel(ArcSplitArgs a) {
                 if (t1 < NTW) acc[t1] = ARC_MFMA(wh[sl][1], xl, acc[t1]);
                 acc[t0] = ARC_MFMA(wh[sl][0], xh, acc[t0]);
                 if (t1 < NTW) acc[t1] = ARC_MFMA(wh[sl][1], xh, acc[t1]);
-                ARC_PIN(acc[t0]);
-                if (t1 < NTW) ARC_PIN(acc[t1]);
                 if constexpr (decltype(issue)::value) {  // the stage's NLW issues spread evenly over its NP pairs
 #pragma unroll
                     for (int q = p * NLW / NP; q < (p + 1) * NLW / NP; ++q) arc_dma16(srcA[q] + so, ld + q * 8192);
@@ -382,14 +366,9 @@ __global__ __launch_bounds__(512, 1) void arc_f16x3_kernel(ArcSplitArgs a) {
                 for (int gi = 0; gi < 4; ++gi) {  // both column tiles whatever L is: branch-free (columns >= L are masked)
                     const int st2 = gi >> 1, k = gi & 1, sl = gi & 1;
                     if (gi + 1 < 4) read_q(gi + 1, sl ^ 1);
-#if !defined(ARC_ABL) || ARC_ABL != 2
                     acc2[k] = ARC_MFMA(tl[st2], qh[sl], acc2[k]);
                     acc2[k] = ARC_MFMA(th[st2], ql[sl], acc2[k]);
                     acc2[k] = ARC_MFMA(th[st2], qh[sl], acc2[k]);
-#else
-                    acc2[k][0] += __uint_as_float(tl[st2][0] ^ qh[sl][0] ^ th[st2][1] ^ ql[sl][1]);
-#endif
-                    ARC_PIN(acc2[k]);
                     if ((gi & 1) && c + DB < NT) arc_dma16(srcB[gi >> 1] + (long)(c + DB) * 128, ld + (gi >> 1) * 8192);
                 }
             } else if (c + DB < NT) {
@@ -397,9 +376,7 @@ __global__ __launch_bounds__(512, 1) void arc_f16x3_kernel(ArcSplitArgs a) {
                 for (int q = 0; q < 2; ++q) arc_dma16(srcB[q] + (long)(c + DB) * 128, ld + q * 8192);
             }
             // the next chunk into the other patch, beside this chunk's MFMAs, by the half that holds it
-#if !defined(ARC_ABL) || ARC_ABL != 1
             if (c + 1 < NT && nh == (c + 1) / NTW && !dead) convert(c + 1, (c + 1) % NTW);
-#endif
         }
         ARC_STAMP(3 + 4 * s);
         // ------------------------------------------------------------------------------------------ the scorer's term

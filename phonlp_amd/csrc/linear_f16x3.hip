@@ -819,7 +819,7 @@ __global__ __launch_bounds__(256, 2) void linear_f16x3_dma_kernel(LinearArgs a) 
 // workgroup, one workgroup per CU), the same LDS image, DMA pattern and MFMA order (al.bh, ah.bl, ah.bh per stage) as
 // above, hence the same bits.  The loop is branch-free: the loads of the stages beyond K re-fetch the last stage into
 // buffers nobody reads again, so one s_waitcnt immediate serves every iteration.
-template <int TAG, int NBUF>
+template <int NBUF>
 __global__ __launch_bounds__(256, 1) void linear_f16x3_small_kernel(LinearArgs a) {
     constexpr int BM = 64, BN = 64, WM = 2, WN = 2, TM = 1, TN = 1;
     constexpr int ROWS = BM + BN, BUF = ROWS * 64;
@@ -1678,9 +1678,9 @@ int launch_linear_f16x3(const char *tag, const void *Xp, long pitch_x, const flo
             static PerDeviceOnce small_once;
             int sdev;
             if (small_once.pending(&sdev)) {
-                if (hipFuncSetAttribute((const void *)linear_f16x3_small_kernel<0, 16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                if (hipFuncSetAttribute((const void *)linear_f16x3_small_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         16 * STAGE_SMALL) != hipSuccess ||
-                    hipFuncSetAttribute((const void *)linear_f16x3_small_kernel<0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                    hipFuncSetAttribute((const void *)linear_f16x3_small_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         8 * STAGE_SMALL) != hipSuccess)
                     return fail(PHONLP_ERR_LAUNCH, "linear_split: cannot raise the dynamic LDS limit");
                 small_once.mark(sdev);
@@ -1689,9 +1689,9 @@ int launch_linear_f16x3(const char *tag, const void *Xp, long pitch_x, const flo
             a.num_n = ceil_div(N, 64);
             ProfScope pss(tag, stream);
             if (nsmall <= 256)
-                hipLaunchKernelGGL((linear_f16x3_small_kernel<0, 16>), dim3((unsigned)nsmall), dim3(256), 16 * STAGE_SMALL, stream, a);
+                hipLaunchKernelGGL((linear_f16x3_small_kernel<16>), dim3((unsigned)nsmall), dim3(256), 16 * STAGE_SMALL, stream, a);
             else
-                hipLaunchKernelGGL((linear_f16x3_small_kernel<0, 8>), dim3((unsigned)nsmall), dim3(256), 8 * STAGE_SMALL, stream, a);
+                hipLaunchKernelGGL((linear_f16x3_small_kernel<8>), dim3((unsigned)nsmall), dim3(256), 8 * STAGE_SMALL, stream, a);
             return check_launch("linear_f16x3_small_kernel");
         }
     }
