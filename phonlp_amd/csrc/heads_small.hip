@@ -1,4 +1,5 @@
 // POS head tail (softmax / arg-max / soft POS embedding), NER emissions, dep_hid, and the error plumbing.
+#include <limits.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -175,6 +176,220 @@ __global__ __launch_bounds__(256) void pos_tail_kernel(const float *enc, long ld
     }
 }
 
+// ---- POS head tail with upos_clf inside (the emb == NULL form of the POS head: the "embedding" columns of feat hold the
+// tag probabilities themselves, [enc | softmax(logits) | 0], which is what the scorers read once upos_emb_matrix_dep has
+// been folded into their first layers).  One launch instead of upos_clf + pos_tail_kernel.
+//
+// A block takes 32 tokens.  logits[token][u] = hid[token] . Wclf[u] as an exact-fp32 MFMA product (v_mfma_f32_32x32x2_f32:
+// rows = tags, columns = tokens), the k range dealt to the four waves in chunks of eight (chunk c to wave c & 3, a lane's
+// float4 of a chunk feeds four MFMAs); the partial tiles are added in wave order through LDS.  The order of a token's sum
+// is fixed and does not depend on the batch or on the token's place in the block.  In the 32 x 32 accumulator layout a
+// lane then holds ONE token (lane & 31) and sixteen of its tags (u = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)), so arg-max
+// (lowest index among equals), softmax and the f16 split of the probabilities are in-lane loops plus one exchange with
+// lane ^ 32, for 32 tokens at once.  Fast path (presplit image, the probabilities' exponent within the enc part's): only
+// the image's probability columns are written, 8 bytes per lane and piece.  Everything else -- padded rows, a row whose
+// scale the probabilities change, no presplit image, the fp32 feat output -- goes token by token through the row buffers
+// like pos_tail_kernel, the flagged tokens dealt to the four waves.
+__device__ __forceinline__ void pos_probs_slow_row(float *row, const float *pr, const float *enc, long ld_enc,
+                                                   const int32_t *sentlens, int tok, int L, int E, int TE, float *feat,
+                                                   unsigned char *planes, float *inv_scale, int lane) {
+    const int D = E + TE, K16 = (D + 15) / 16 * 16;
+    const int b = tok / L, i = tok - b * L;
+    float *frow = feat ? feat + (long)tok * D : nullptr;
+    unsigned char *prow = planes ? planes + (long)tok * K16 * 4 : nullptr;
+    if (i >= sentlens[b]) {
+        if (frow)
+            for (int c = lane * 4; c < D; c += 256) *reinterpret_cast<float4 *>(frow + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (prow) {
+            for (int c = lane * 16; c < K16 * 4; c += 1024) *reinterpret_cast<uint4 *>(prow + c) = make_uint4(0, 0, 0, 0);
+            if (lane == 0) inv_scale[tok] = 1.f;
+        }
+        return;
+    }
+    unsigned mx = 0;
+    for (int d = lane; E + d < K16; d += 64) {
+        const float v = (d < 32 && d < TE) ? pr[d] : 0.f;
+        row[E + d] = v;
+        mx = max(mx, __float_as_uint(v) & 0x7FFFFFFFu);
+    }
+    const float *erow = enc + (long)tok * ld_enc;
+    for (int c = lane * 4; c < E; c += 256) {
+        const float4 v = *reinterpret_cast<const float4 *>(erow + c);
+        *reinterpret_cast<float4 *>(row + c) = v;
+        mx = max(max(mx, __float_as_uint(v.x) & 0x7FFFFFFFu), max(__float_as_uint(v.y) & 0x7FFFFFFFu,
+                 max(__float_as_uint(v.z) & 0x7FFFFFFFu, __float_as_uint(v.w) & 0x7FFFFFFFu)));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (frow)
+        for (int c = lane * 4; c < D; c += 256) *reinterpret_cast<float4 *>(frow + c) = *reinterpret_cast<const float4 *>(row + c);
+    if (prow) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
+        int Ex = (int)(mx >> 23);
+        Ex = Ex < 16 ? 16 : (Ex > 254 ? 254 : Ex);
+        if (lane == 0) inv_scale[tok] = __uint_as_float((unsigned)(Ex - 14) << 23);
+        const float scale = __uint_as_float((unsigned)(268 - Ex) << 23);
+        for (int g = lane; g * 8 < K16; g += 64) {
+            h16x8 h, l;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float sv = row[g * 8 + e] * scale;
+                h[e] = (_Float16)sv;
+                l[e] = (_Float16)(sv - (float)h[e]);
+            }
+            *reinterpret_cast<h16x8 *>(prow + g * 32) = h;
+            *reinterpret_cast<h16x8 *>(prow + g * 32 + 16) = l;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the row buffer is reused by this wave's next token
+}
+
+typedef float pf32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+constexpr int kProbPitch = 33;
+
+__global__ __launch_bounds__(256) void pos_clf_tail_kernel(const float *hid, long ldh, const float *Wclf, const float *bclf,
+                                                           const float *enc, long ld_enc, const int32_t *sentlens, int M,
+                                                           int L, int E, int H, int U, int TE, float *feat,
+                                                           int32_t *pos_pred, float *logits_out, unsigned char *planes,
+                                                           float *inv_scale, int presplit) {
+    extern __shared__ __attribute__((aligned(16))) float psm[];
+    float *part = psm;                       // [3][16][64] partial logit tiles of waves 1-3
+    float *prob = part + 3 * 1024;           // [32][kProbPitch]
+    int *flags = reinterpret_cast<int *>(prob + 32 * kProbPitch);  // [0] = mask of the tokens left to the slow path
+    float *rows = prob + 32 * kProbPitch + 32;                     // [4][K16]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int D = E + TE, K16 = (D + 15) / 16 * 16;
+    const int tok0 = blockIdx.x * 32, n = lane & 31, hf = lane >> 5;
+    const int tok = tok0 + n;
+    const bool tv = tok < M;
+    pf32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    {
+        const float *hrow = hid + (long)(tv ? tok : 0) * ldh;
+        const float *wrow = Wclf + (long)(n < U ? n : 0) * H;
+        const int NC = (H + 7) >> 3;
+        for (int c0 = wave; c0 < NC; c0 += 16) {  // four chunks' loads in flight (chunks beyond the end: zeros, which add nothing)
+            float4 a4[4], b4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = 8 * (c0 + 4 * j) + 4 * hf;
+                a4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                b4[j] = a4[j];
+                if (k < H) {
+                    if (n < U) a4[j] = *reinterpret_cast<const float4 *>(wrow + k);
+                    if (tv) b4[j] = *reinterpret_cast<const float4 *>(hrow + k);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].x, b4[j].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].y, b4[j].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].z, b4[j].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].w, b4[j].w, acc, 0, 0, 0);
+            }
+        }
+    }
+    if (wave) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[((wave - 1) * 16 + r) * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const int b = tv ? tok / L : 0, i = tok - b * L;
+        const bool live = tv && i < sentlens[b];
+        float lg[16];
+        float best = -INFINITY;
+        int bi = INT_MAX;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int u = (r & 3) + 8 * (r >> 2) + 4 * hf;
+            const float sum = ((acc[r] + part[r * 64 + lane]) + part[(16 + r) * 64 + lane]) + part[(32 + r) * 64 + lane];
+            lg[r] = u < U ? sum + bclf[u] : -INFINITY;
+            if (lg[r] > best) { best = lg[r]; bi = u; }
+        }
+        {
+            const float v2 = __shfl_xor(best, 32);
+            const int i2 = __shfl_xor(bi, 32);
+            if (v2 > best || (v2 == best && i2 < bi)) { best = v2; bi = i2; }
+        }
+        if (bi == INT_MAX) bi = 0;
+        if (logits_out && tv) {  // padded rows: zeros, as the masked layer writes them
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int u0 = 8 * q + 4 * hf;
+                float *dst = logits_out + (long)tok * U + u0;
+                if (u0 + 3 < U && !(U & 3)) {
+                    *reinterpret_cast<float4 *>(dst) = live ? make_float4(lg[4 * q], lg[4 * q + 1], lg[4 * q + 2], lg[4 * q + 3])
+                                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (u0 + e < U) dst[e] = live ? lg[4 * q + e] : 0.f;
+                }
+            }
+        }
+        if (pos_pred && tv && hf == 0) pos_pred[tok] = live ? bi : 0;
+        float p[16], s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            p[r] = lg[r] > -INFINITY ? expf(lg[r] - best) : 0.f;
+            s += p[r];
+        }
+        s += __shfl_xor(s, 32);
+        unsigned mx = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            p[r] = p[r] / s;
+            mx = max(mx, __float_as_uint(p[r]) & 0x7FFFFFFFu);
+            prob[n * kProbPitch + (r & 3) + 8 * (r >> 2) + 4 * hf] = p[r];
+        }
+        mx = max(mx, (unsigned)__shfl_xor((int)mx, 32));
+        int Ee = (int)(mx >> 23);
+        Ee = Ee < 16 ? 16 : (Ee > 254 ? 254 : Ee);
+        bool fast = live && planes && presplit && !feat;
+        int Ex = 0;
+        if (fast) {
+            Ex = (int)(__float_as_uint(inv_scale[tok]) >> 23) + 14;  // the enc part's exponent (split_rows_kernel)
+            if (Ee > Ex) fast = false;
+        }
+        if (fast) {
+            const float scale = __uint_as_float((unsigned)(268 - Ex) << 23);
+            unsigned char *prow = planes + (long)tok * K16 * 4 + (E >> 3) * 32 + hf * 8;
+            const int G = (K16 - E) >> 3;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (q < G) {
+                    h16x4 h, l;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float sv = p[4 * q + e] * scale;
+                        h[e] = (_Float16)sv;
+                        l[e] = (_Float16)(sv - (float)h[e]);
+                    }
+                    *reinterpret_cast<h16x4 *>(prow + q * 32) = h;
+                    *reinterpret_cast<h16x4 *>(prow + q * 32 + 16) = l;
+                }
+            }
+            for (int q = 4; q < G; ++q) {  // (TE <= 32: columns beyond the tags are zero)
+                *reinterpret_cast<uint2 *>(prow + q * 32) = make_uint2(0, 0);
+                *reinterpret_cast<uint2 *>(prow + q * 32 + 16) = make_uint2(0, 0);
+            }
+        }
+        const unsigned long long slow = __ballot(tv && !fast && hf == 0);
+        if (lane == 0) flags[0] = (int)(unsigned)slow;
+    }
+    __syncthreads();
+    unsigned mask = (unsigned)flags[0];
+    float *row = rows + wave * K16;
+    for (int idx = 0; mask; ++idx) {
+        const int n2 = __ffs((int)mask) - 1;
+        mask &= mask - 1;
+        if ((idx & 3) == wave)
+            pos_probs_slow_row(row, prob + n2 * kProbPitch, enc, ld_enc, sentlens, tok0 + n2, L, E, TE, feat, planes, inv_scale, lane);
+    }
+}
 
 // Tail of the fused tagger head (phonlp_tagger_head): one wavefront per token.  logits [M, U] -> pos_pred and the soft POS
 // embedding e = softmax(logits) . emb as in pos_tail_kernel; then the NER emissions
@@ -303,9 +518,12 @@ static int pos_head_impl(const float *enc, int ld_enc, const int32_t *sentlens, 
                          const float *bhid, const float *Wclf, const float *bclf, const float *emb, int H, int U, int TE,
                          float *feat, int32_t *pos_pred, float *upos_logits, void *feat_planes, float *feat_inv_scale,
                          void *ws, size_t ws_bytes, void *stream) {
-    if (!enc || !sentlens || !Whid || !bhid || !Wclf || !bclf || !emb || (!feat && !feat_planes) || B <= 0 || L <= 0)
+    if (!enc || !sentlens || !Whid || !bhid || !Wclf || !bclf || (!feat && !feat_planes) || B <= 0 || L <= 0)
         return fail(PHONLP_ERR_SHAPE, "pos_head: bad argument");
     if (U > 64 || U <= 0) return fail(PHONLP_ERR_UNSUPPORTED, "pos_head: needs 1 <= U <= 64 (one lane per tag)");
+    // emb == NULL: the embedding columns hold the tag probabilities themselves (pos_clf_tail_kernel: upos_clf inside the tail)
+    if (!emb && (U > 32 || TE < U || TE > 32))
+        return fail(PHONLP_ERR_UNSUPPORTED, "pos_head: emb == NULL (probabilities as the embedding) needs U <= TE <= 32");
     if ((E & 3) || (H & 3) || ((E + TE) & 3) || (ld_enc & 3) || ((uintptr_t)feat & 15) || ((uintptr_t)feat_planes & 15))
         return fail(PHONLP_ERR_SHAPE, "pos_head: E, H, E+TE, ld_enc must be multiples of 4 and feat 16-byte aligned");
     if ((feat_planes != nullptr) != (feat_inv_scale != nullptr))
@@ -342,10 +560,18 @@ static int pos_head_impl(const float *enc, int ld_enc, const int32_t *sentlens, 
         rc = launch_linear("linear:upos_hid", enc, ld_enc, Whid, E, bhid, hid, H, M, H, E, 1, sentlens, L, st);
     }
     if (rc) return rc;
+    const size_t lds = 4 * (size_t)((E + TE + 15) / 16 * 16) * sizeof(float);
+    const size_t lds_fused = lds + (3 * 1024 + 32 * kProbPitch + 32) * sizeof(float);
+    if ((emb ? lds : lds_fused) > 64 * 1024) return fail(PHONLP_ERR_UNSUPPORTED, "pos_head: E + TE too large for the row buffers");
+    if (!emb) {
+        ProfScope ps("pos_tail", st);
+        hipLaunchKernelGGL(pos_clf_tail_kernel, dim3(ceil_div(M, 32)), dim3(256), lds_fused, st, hid, (long)H, Wclf, bclf, enc,
+                           (long)ld_enc, sentlens, M, L, E, H, U, TE, feat, pos_pred, upos_logits,
+                           (unsigned char *)feat_planes, feat_inv_scale, presplit);
+        return check_launch("pos_clf_tail_kernel");
+    }
     rc = launch_linear("linear:upos_clf", hid, H, Wclf, H, bclf, logits, U, M, U, H, 0, sentlens, L, st);
     if (rc) return rc;
-    const size_t lds = 4 * (size_t)((E + TE + 15) / 16 * 16) * sizeof(float);
-    if (lds > 64 * 1024) return fail(PHONLP_ERR_UNSUPPORTED, "pos_head: E + TE too large for the row buffers");
     ProfScope ps("pos_tail", st);
     hipLaunchKernelGGL(pos_tail_kernel, dim3(ceil_div(M, 4)), dim3(256), lds, st, enc, (long)ld_enc, logits, emb, sentlens,
                        M, L, E, U, TE, feat, pos_pred, (unsigned char *)feat_planes, feat_inv_scale, presplit);

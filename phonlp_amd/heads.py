@@ -785,6 +785,8 @@ class TaskHeads:
                 # the embedding is folded into the scorers' weights: the "feat" image is [enc | tag probabilities]
                 emb, arcW, labW = w.emb_eye, w.arc_W12p_s, w.lab_W12p_s
                 D = enc_dep.shape[2] + emb.shape[1]
+                if emb.shape[0] <= 32:  # upos_clf inside the POS tail (pos_clf_tail_kernel): one launch for two
+                    emb = None
             # the arc scorers' two bilinear stages as ONE kernel on the image their first layer writes (csrc/arc_f16x3.hip)
             arc_fused = cfg["arc_fused"] and w.arc_W12q_s is not None and Ld <= 512 and w.arc_W12p_s is not None
             if pack:

@@ -909,15 +909,22 @@ def ner_entity_counts_into(counts: Tensor, pred: Tensor, gold: Tensor, sentlens:
                                          tag_kind.numel(), _p(counts), _stream()), "phonlp_ner_entity_counts")
 
 
+def probs_width(U: int) -> int:
+    """Columns the tag probabilities take in a feat row when they stand in for the soft POS embedding (emb=None)."""
+    return (U + 3) // 4 * 4
+
+
 @torch.library.custom_op("phonlp_amd::pos_head_split", mutates_args=())
-def pos_head_split(enc: Tensor, sentlens: Tensor, Whid: Tensor, bhid: Tensor, Wclf: Tensor, bclf: Tensor, emb: Tensor,
-                   want_feat: bool) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor]:
+def pos_head_split(enc: Tensor, sentlens: Tensor, Whid: Tensor, bhid: Tensor, Wclf: Tensor, bclf: Tensor,
+                   emb: Optional[Tensor], want_feat: bool) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor]:
     """pos_head whose feat rows come out as an engine-2 split image: -> (planes uint8 [B*L, 4*K16], inv_scale [B*L],
-    pos_pred int32 [B,L], upos_logits [B,L,U], feat [B,L,E+TE] or an empty tensor)."""
+    pos_pred int32 [B,L], upos_logits [B,L,U], feat [B,L,E+TE] or an empty tensor).  emb=None (U <= 32): the embedding
+    columns hold the tag probabilities themselves, TE = U rounded up to 4 (upos_clf computed inside the tail kernel)."""
     _need(enc, torch.float32, "enc")
     _need(sentlens, torch.int32, "sentlens")
     B, L, E = enc.shape
-    H, U, TE = Whid.shape[0], Wclf.shape[0], emb.shape[1]
+    H, U = Whid.shape[0], Wclf.shape[0]
+    TE = emb.shape[1] if emb is not None else probs_width(U)
     dev = enc.device
     D = E + TE
     planes = torch.empty((B * L, lib().phonlp_split_bytes(1, D)), dtype=torch.uint8, device=dev)
@@ -1081,7 +1088,7 @@ def _(x1p, x1_inv, wbtp, wbt_inv, B, L, H, O, ones_col=None):
 @pos_head_split.register_fake
 def _(enc, sentlens, Whid, bhid, Wclf, bclf, emb, want_feat):
     B, L, E = enc.shape
-    D = E + emb.shape[1]
+    D = E + (emb.shape[1] if emb is not None else probs_width(Wclf.shape[0]))
     return (enc.new_empty((B * L, lib().phonlp_split_bytes(1, D)), dtype=_U8), enc.new_empty((B * L,)),
             enc.new_empty((B, L), dtype=_I32), enc.new_empty((B, L, Wclf.shape[0])),
             enc.new_empty((B, L, D) if want_feat else (0,)))

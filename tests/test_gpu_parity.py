@@ -789,6 +789,63 @@ def test_pos_head_split_image(dev, B, L, E, TE, H, U, emb_scale):
             assert torch.equal(feat1, feat0)
 
 
+def _image_rows(planes, inv, K):
+    """Split image -> the fp64 rows it stands for ((h + l) * inv_scale), first K columns."""
+    rows = planes.shape[0]
+    K16 = (K + 15) // 16 * 16
+    img = planes.cpu().view(torch.float16).view(rows, K16 // 8, 2, 8).double()
+    rec = (img[:, :, 0, :] + img[:, :, 1, :]).reshape(rows, K16) * inv.cpu().double().unsqueeze(1)
+    assert (rec[:, K:] == 0).all()
+    return rec[:, :K]
+
+
+@pytest.mark.parametrize("B,L,E,H,U,enc_scale", [(7, 33, 64, 24, 7, 1.0), (9, 21, 64, 24, 7, 1e-3), (5, 19, 24, 16, 7, 1.0),
+                                                  (3, 9, 20, 8, 3, 1.0), (4, 37, 64, 44, 32, 1.0), (6, 50, 64, 100, 17, 0.05),
+                                                  (16, 128, 768, 400, 24, 1.0), (1, 32, 768, 400, 24, 1.0)])
+def test_pos_head_probs_fused(dev, engine, B, L, E, H, U, enc_scale):
+    """pos_head_split(emb=None) -- upos_clf inside the tail kernel, the tag probabilities where the embedding was -- against
+    the two-launch form with emb = eye(U, Up): logits to fp32 rounding (another summation order), POS ids equal except
+    provable near-ties, the image's rows equal to 1e-6 of the row maximum, padded rows zero planes and zero ids.
+    enc_scale << 1 takes the redo-the-row path (the probabilities exceed the enc part's exponent), E % 8 != 0 the path
+    without a presplit image, want_feat the fp32 rows; and a sentence's rows do not depend on the batch around it."""
+    from phonlp_amd import HeadWeights, ops
+    from phonlp_amd import synthetic as S
+    TE0 = 12
+    sd = S.make_state_dict(E, TE0, H, U, 5, 5, seed=B + U)
+    w = HeadWeights.from_state_dict(sd, dev)
+    g = torch.Generator().manual_seed(L)
+    enc = (torch.randn(B, L, E, generator=g) * enc_scale).to(dev)
+    lens = torch.randint(1, L + 1, (B,), generator=g).to(torch.int32)
+    lens[0] = L
+    lens_d = lens.to(dev)
+    Up = ops.probs_width(U)
+    eye = torch.eye(U, Up, device=dev)
+    live = (torch.arange(L)[None, :] < lens[:, None]).reshape(-1)
+    p0, i0, pos0, log0, feat0 = ops.pos_head_split(enc, lens_d, w.upos_hid_w, w.upos_hid_b, w.upos_clf_w, w.upos_clf_b, eye, True)
+    rows0 = _image_rows(p0, i0, E + Up)
+    for want_feat in (False, True):
+        p1, i1, pos1, log1, feat1 = ops.pos_head_split(enc, lens_d, w.upos_hid_w, w.upos_hid_b, w.upos_clf_w, w.upos_clf_b,
+                                                       None, want_feat)
+        _close(log1, log0, rtol=1e-5, atol=2e-6)
+        _near_tie_ok(pos1.cpu(), pos0.cpu(), log0.cpu(), 1e-5)
+        assert (pos1.cpu().reshape(-1)[~live] == 0).all() and (log1.cpu().reshape(B * L, U)[~live] == 0).all()
+        assert (p1.cpu()[~live] == 0).all() and (i1.cpu()[~live] == 1).all()
+        rows1 = _image_rows(p1, i1, E + Up)
+        tol = 1e-6 * rows0.abs().max(1, keepdim=True).values.clamp_min(1e-30)
+        assert ((rows1 - rows0).abs()[live] <= tol[live]).all()
+        if want_feat:
+            _close(feat1, feat0, rtol=1e-5, atol=1e-6)
+            # the image is split_rows of the fp32 rows, bit for bit
+            pf, iv = ops.split_rows(feat1.view(B * L, E + Up))
+            assert torch.equal(pf.cpu()[live], p1.cpu()[live]) and torch.equal(iv.cpu()[live], i1.cpu()[live])
+    # sub-batch identity: the first two sentences alone give the same bits
+    nb = min(B, 2)
+    p2, i2, pos2, log2, _ = ops.pos_head_split(enc[:nb].contiguous(), lens_d[:nb].contiguous(), w.upos_hid_w, w.upos_hid_b,
+                                               w.upos_clf_w, w.upos_clf_b, None, False)
+    assert torch.equal(p2, p1[:nb * L]) and torch.equal(i2, i1[:nb * L]) and torch.equal(pos2, pos1[:nb])
+    assert torch.equal(log2, log1[:nb])
+
+
 @pytest.mark.parametrize("B,L,E,TE,H,U,T", [(7, 33, 64, 12, 24, 7, 5), (5, 19, 24, 8, 16, 7, 3), (2, 4, 20, 4, 8, 3, 70),
                                              (16, 127, 768, 100, 400, 24, 9)])
 def test_fused_tagger_head(dev, engine, B, L, E, TE, H, U, T):
