@@ -118,6 +118,9 @@ int phonlp_pack_bilinear(const float *weight, int H, int O, float *Wbt, void *st
  *   feat = [enc | softmax(logits) . emb]      (the 768+100 input of the next layer)
  * enc: [B*L, E] (ld_enc floats per row).  feat: [B*L, E+TE] (padded rows zero).
  * pos_pred [B*L] and upos_logits [B*L, U] are optional (NULL to skip).
+ * emb == NULL (U <= TE <= 32): the embedding is the identity, feat = [enc | softmax(logits) | 0] -- what the scorers
+ * read once upos_emb_matrix_dep is folded into their first layers (W[:, E:] . emb^T); upos_clf then runs inside the tail
+ * kernel (one launch for two; the 400-term sums in a fixed order of their own, the same for every batch size).
  */
 size_t phonlp_pos_head_ws_bytes(int B, int L, int E, int H, int U, int TE);
 int phonlp_pos_head(const float *enc, int ld_enc, const int32_t *sentlens, int B, int L, int E,
@@ -140,7 +143,9 @@ int phonlp_pos_head_split(const float *enc, int ld_enc, const int32_t *sentlens,
  * kernel.  Whn [H+T, E] = upos_hid.weight rows followed by ner_tag_clf.weight[:, :E]; bhn [H+T] = upos_hid.bias followed
  * by zeros; Wner_emb [T, TE] = ner_tag_clf.weight[:, E:]; emb = upos_emb_matrix_ner [U, TE].  Same results as
  * phonlp_pos_head + phonlp_ner_emission to fp32 rounding (the 868-term dot product is summed in another order).
- * pos_pred [B*L], ner_logits [B*L, T]; upos_logits [B*L, U] optional (NULL to skip). */
+ * pos_pred [B*L], ner_logits [B*L, T]; upos_logits [B*L, U] optional (NULL to skip).
+ * emb == NULL (TE == U <= 32): the embedding is the identity and Wner_emb [T, U] = ner_tag_clf.weight[:, E:] . emb^T, folded
+ * by the caller at load; upos_clf then runs inside the tail kernel as in phonlp_pos_head. */
 size_t phonlp_tagger_head_ws_bytes(int B, int L, int E, int H, int U, int TE, int T);
 int phonlp_tagger_head(const float *enc, int ld_enc, const int32_t *sentlens, int B, int L, int E,
                        const float *Whn, const float *bhn, const float *Wclf, const float *bclf, const float *emb,

@@ -248,21 +248,10 @@ typedef float pf32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 constexpr int kProbPitch = 33;
 
-__global__ __launch_bounds__(256) void pos_clf_tail_kernel(const float *hid, long ldh, const float *Wclf, const float *bclf,
-                                                           const float *enc, long ld_enc, const int32_t *sentlens, int M,
-                                                           int L, int E, int H, int U, int TE, float *feat,
-                                                           int32_t *pos_pred, float *logits_out, unsigned char *planes,
-                                                           float *inv_scale, int presplit) {
-    extern __shared__ __attribute__((aligned(16))) float psm[];
-    float *part = psm;                       // [3][16][64] partial logit tiles of waves 1-3
-    float *prob = part + 3 * 1024;           // [32][kProbPitch]
-    int *flags = reinterpret_cast<int *>(prob + 32 * kProbPitch);  // [0] = mask of the tokens left to the slow path
-    float *rows = prob + 32 * kProbPitch + 32;                     // [4][K16]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int D = E + TE, K16 = (D + 15) / 16 * 16;
-    const int tok0 = blockIdx.x * 32, n = lane & 31, hf = lane >> 5;
-    const int tok = tok0 + n;
-    const bool tv = tok < M;
+// This wave's share of logits[token][u] = hid[token] . Wclf[u] for the block's 32 tokens: k chunks wave, wave + 4, ... of
+// eight, lane (n, hf) feeding Wclf[n][8c + 4hf ..] and hid[token n][8c + 4hf ..] to four v_mfma_f32_32x32x2_f32.
+__device__ __forceinline__ pf32x16 pos_logits_partial(const float *hid, long ldh, const float *Wclf, int H, int U, int tok,
+                                                      bool tv, int n, int hf, int wave) {
     pf32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -291,6 +280,74 @@ __global__ __launch_bounds__(256) void pos_clf_tail_kernel(const float *hid, lon
             }
         }
     }
+    return acc;
+}
+
+// Wave 0, after the partial tiles are in LDS: the token's logits (partials added in wave order, + bias), arg-max with the
+// lowest index among equals, optional logits / POS id outputs (padded rows: zeros), and the tag probabilities p[r] of
+// tag u = (r & 3) + 8 (r >> 2) + 4 hf (0 beyond U).
+__device__ __forceinline__ void pos_tile_softmax(const pf32x16 &acc, const float *part, const float *bclf, int U, int hf, int lane,
+                                                 int tok, bool tv, bool live, float *logits_out, int32_t *pos_pred,
+                                                 float (&p)[16]) {
+    float lg[16];
+    float best = -INFINITY;
+    int bi = INT_MAX;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int u = (r & 3) + 8 * (r >> 2) + 4 * hf;
+        const float sum = ((acc[r] + part[r * 64 + lane]) + part[(16 + r) * 64 + lane]) + part[(32 + r) * 64 + lane];
+        lg[r] = u < U ? sum + bclf[u] : -INFINITY;
+        if (lg[r] > best) { best = lg[r]; bi = u; }
+    }
+    {
+        const float v2 = __shfl_xor(best, 32);
+        const int i2 = __shfl_xor(bi, 32);
+        if (v2 > best || (v2 == best && i2 < bi)) { best = v2; bi = i2; }
+    }
+    if (bi == INT_MAX) bi = 0;
+    if (logits_out && tv) {  // padded rows: zeros, as the masked layer writes them
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int u0 = 8 * q + 4 * hf;
+            float *dst = logits_out + (long)tok * U + u0;
+            if (u0 + 3 < U && !(U & 3)) {
+                *reinterpret_cast<float4 *>(dst) = live ? make_float4(lg[4 * q], lg[4 * q + 1], lg[4 * q + 2], lg[4 * q + 3])
+                                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (u0 + e < U) dst[e] = live ? lg[4 * q + e] : 0.f;
+            }
+        }
+    }
+    if (pos_pred && tv && hf == 0) pos_pred[tok] = live ? bi : 0;
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        p[r] = lg[r] > -INFINITY ? expf(lg[r] - best) : 0.f;
+        s += p[r];
+    }
+    s += __shfl_xor(s, 32);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) p[r] = p[r] / s;
+}
+
+__global__ __launch_bounds__(256) void pos_clf_tail_kernel(const float *hid, long ldh, const float *Wclf, const float *bclf,
+                                                           const float *enc, long ld_enc, const int32_t *sentlens, int M,
+                                                           int L, int E, int H, int U, int TE, float *feat,
+                                                           int32_t *pos_pred, float *logits_out, unsigned char *planes,
+                                                           float *inv_scale, int presplit) {
+    extern __shared__ __attribute__((aligned(16))) float psm[];
+    float *part = psm;                       // [3][16][64] partial logit tiles of waves 1-3
+    float *prob = part + 3 * 1024;           // [32][kProbPitch]
+    int *flags = reinterpret_cast<int *>(prob + 32 * kProbPitch);  // [0] = mask of the tokens left to the slow path
+    float *rows = prob + 32 * kProbPitch + 32;                     // [4][K16]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int D = E + TE, K16 = (D + 15) / 16 * 16;
+    const int tok0 = blockIdx.x * 32, n = lane & 31, hf = lane >> 5;
+    const int tok = tok0 + n;
+    const bool tv = tok < M;
+    pf32x16 acc = pos_logits_partial(hid, ldh, Wclf, H, U, tok, tv, n, hf, wave);
     if (wave) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) part[((wave - 1) * 16 + r) * 64 + lane] = acc[r];
@@ -299,49 +356,11 @@ __global__ __launch_bounds__(256) void pos_clf_tail_kernel(const float *hid, lon
     if (wave == 0) {
         const int b = tv ? tok / L : 0, i = tok - b * L;
         const bool live = tv && i < sentlens[b];
-        float lg[16];
-        float best = -INFINITY;
-        int bi = INT_MAX;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int u = (r & 3) + 8 * (r >> 2) + 4 * hf;
-            const float sum = ((acc[r] + part[r * 64 + lane]) + part[(16 + r) * 64 + lane]) + part[(32 + r) * 64 + lane];
-            lg[r] = u < U ? sum + bclf[u] : -INFINITY;
-            if (lg[r] > best) { best = lg[r]; bi = u; }
-        }
-        {
-            const float v2 = __shfl_xor(best, 32);
-            const int i2 = __shfl_xor(bi, 32);
-            if (v2 > best || (v2 == best && i2 < bi)) { best = v2; bi = i2; }
-        }
-        if (bi == INT_MAX) bi = 0;
-        if (logits_out && tv) {  // padded rows: zeros, as the masked layer writes them
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int u0 = 8 * q + 4 * hf;
-                float *dst = logits_out + (long)tok * U + u0;
-                if (u0 + 3 < U && !(U & 3)) {
-                    *reinterpret_cast<float4 *>(dst) = live ? make_float4(lg[4 * q], lg[4 * q + 1], lg[4 * q + 2], lg[4 * q + 3])
-                                                            : make_float4(0.f, 0.f, 0.f, 0.f);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (u0 + e < U) dst[e] = live ? lg[4 * q + e] : 0.f;
-                }
-            }
-        }
-        if (pos_pred && tv && hf == 0) pos_pred[tok] = live ? bi : 0;
-        float p[16], s = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            p[r] = lg[r] > -INFINITY ? expf(lg[r] - best) : 0.f;
-            s += p[r];
-        }
-        s += __shfl_xor(s, 32);
+        float p[16];
+        pos_tile_softmax(acc, part, bclf, U, hf, lane, tok, tv, live, logits_out, pos_pred, p);
         unsigned mx = 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            p[r] = p[r] / s;
             mx = max(mx, __float_as_uint(p[r]) & 0x7FFFFFFFu);
             prob[n * kProbPitch + (r & 3) + 8 * (r >> 2) + 4 * hf] = p[r];
         }
@@ -452,6 +471,50 @@ __global__ __launch_bounds__(256) void tagger_tail_kernel(const float *hid, long
             ner[(long)tok * T + t0 + lane] = fmaxf(v, 0.f);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+}
+
+
+// The fused tagger head's tail with upos_clf inside (the emb == NULL form of phonlp_tagger_head, U <= 32): logits, arg-max and
+// softmax as in pos_clf_tail_kernel, then
+//   ner[t] = relu(hid[tok][H + t] + sum_u p[u] Wg[t][u] + bner[t]),   Wg = Wne . emb^T  [T, U] (folded by the caller at load),
+// i.e. the soft POS embedding e = p . emb contracted with Wne in the other order: no e row, no per-token pass over Wne.
+__global__ __launch_bounds__(256) void tagger_clf_tail_kernel(const float *hid, long ldh, const float *Wclf, const float *bclf,
+                                                              const float *Wg, const float *bner, const int32_t *sentlens,
+                                                              int M, int L, int H, int U, int T, int32_t *pos_pred,
+                                                              float *logits_out, float *ner) {
+    extern __shared__ __attribute__((aligned(16))) float psm[];
+    float *part = psm;           // [3][16][64]
+    float *G = part + 3 * 1024;  // [U][T]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tok0 = blockIdx.x * 32, n = lane & 31, hf = lane >> 5;
+    const int tok = tok0 + n;
+    const bool tv = tok < M;
+    pf32x16 acc = pos_logits_partial(hid, ldh, Wclf, H, U, tok, tv, n, hf, wave);
+    for (int e = tid; e < U * T; e += 256) {  // G[u][t] = Wg[t][u]
+        const int u = e / T, t = e - u * T;
+        G[e] = Wg[(long)t * U + u];
+    }
+    if (wave) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[((wave - 1) * 16 + r) * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    const int b = tv ? tok / L : 0, i = tok - b * L;
+    const bool live = tv && i < sentlens[b];
+    float p[16];
+    pos_tile_softmax(acc, part, bclf, U, hf, lane, tok, tv, live, logits_out, pos_pred, p);
+    const float *hrow = hid + (long)(tv ? tok : 0) * ldh + H;
+    for (int t = 0; t < T; ++t) {
+        float dot = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int u = (r & 3) + 8 * (r >> 2) + 4 * hf;
+            dot = fmaf(p[r], G[(u < U ? u : 0) * T + t], dot);  // p = 0 beyond U
+        }
+        dot += __shfl_xor(dot, 32);
+        if (tv && hf == 0) ner[(long)tok * T + t] = live ? fmaxf((hrow[t] + dot) + bner[t], 0.f) : 0.f;
     }
 }
 
@@ -611,10 +674,12 @@ extern "C" int phonlp_tagger_head(const float *enc, int ld_enc, const int32_t *s
                                   const float *emb, const float *Wner_emb, const float *bner, int H, int U, int TE, int T,
                                   int32_t *pos_pred, float *ner_logits, float *upos_logits, void *ws, size_t ws_bytes,
                                   void *stream) {
-    if (!enc || !sentlens || !Whn || !bhn || !Wclf || !bclf || !emb || !Wner_emb || !bner || !pos_pred || !ner_logits ||
+    if (!enc || !sentlens || !Whn || !bhn || !Wclf || !bclf || !Wner_emb || !bner || !pos_pred || !ner_logits ||
         B <= 0 || L <= 0 || T <= 0)
         return fail(PHONLP_ERR_SHAPE, "tagger_head: bad argument");
     if (U > 64 || U <= 0) return fail(PHONLP_ERR_UNSUPPORTED, "tagger_head: needs 1 <= U <= 64 (one lane per tag)");
+    if (!emb && (U > 32 || TE != U || (3 * 1024 + (size_t)U * T) * sizeof(float) > 64 * 1024))
+        return fail(PHONLP_ERR_UNSUPPORTED, "tagger_head: emb == NULL (identity embedding, Wner_emb [T, U]) needs TE == U <= 32");
     if ((E & 3) || (H & 3) || (ld_enc & 3)) return fail(PHONLP_ERR_SHAPE, "tagger_head: E, H, ld_enc must be multiples of 4");
     if (!ws || ws_bytes < phonlp_tagger_head_ws_bytes(B, L, E, H, U, TE, T))
         return fail(PHONLP_ERR_WORKSPACE, "tagger_head: workspace too small");
@@ -641,6 +706,12 @@ extern "C" int phonlp_tagger_head(const float *enc, int ld_enc, const int32_t *s
         rc = launch_linear("linear:upos_hid", enc, ld_enc, Whn, E, bhn, hid, HN, M, N, E, -H, sentlens, L, st);
     }
     if (rc) return rc;
+    if (!emb) {  // identity embedding, Wner_emb [T, U]: upos_clf inside the tail
+        ProfScope ps("tagger_tail", st);
+        hipLaunchKernelGGL(tagger_clf_tail_kernel, dim3(ceil_div(M, 32)), dim3(256), (3 * 1024 + (size_t)U * T) * sizeof(float), st,
+                           hid, (long)HN, Wclf, bclf, Wner_emb, bner, sentlens, M, L, H, U, T, pos_pred, upos_logits, ner_logits);
+        return check_launch("tagger_clf_tail_kernel");
+    }
     rc = launch_linear("linear:upos_clf", hid, HN, Wclf, H, bclf, logits, U, M, U, H, 0, sentlens, L, st);
     if (rc) return rc;
     ProfScope ps("tagger_tail", st);

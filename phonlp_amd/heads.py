@@ -62,6 +62,7 @@ class HeadWeights:
     tag_Whn: Optional[torch.Tensor] = None
     tag_bhn: Optional[torch.Tensor] = None
     ner_w_emb: Optional[torch.Tensor] = None
+    ner_w_tags: Optional[torch.Tensor] = None
     lab_ones_col: Optional[torch.Tensor] = None  # column H of lab_Wbt: the weights that meet X1's ones column
     # dep_hid AND the soft POS embedding folded into the scorers' first layers: input columns = [enc | tag probabilities]
     # (split images; emb_eye [U, Up] makes the POS tail write the probabilities where it wrote the embedding)
@@ -179,6 +180,9 @@ class HeadWeights:
             tag_Whn=torch.cat([g("upos_hid.weight"), g("ner_tag_clf.weight")[:, :E_]], 0).contiguous(),
             tag_bhn=torch.cat([g("upos_hid.bias"), torch.zeros_like(g("ner_tag_clf.bias"))], 0).contiguous(),
             ner_w_emb=g("ner_tag_clf.weight")[:, E_:].contiguous(),
+            # ... and with upos_emb_matrix_ner folded in (float64, one rounding): ner_tag_clf.weight[:, E:] @ emb^T [T, U]
+            ner_w_tags=(sd["ner_tag_clf.weight"].detach().double().cpu()[:, E_:]
+                        @ sd["upos_emb_matrix_ner"].detach().double().cpu().T).to(device=device, dtype=torch.float32).contiguous(),
             lab_ones_col=lab[2][:, H].contiguous(),
             arc_W12p_s=tuple(ops.split_rows(arcp)), lab_W12p_s=tuple(ops.split_rows(labp)),
             emb_eye=torch.eye(U_, Up, dtype=torch.float32, device=device).contiguous(),
@@ -743,7 +747,9 @@ class TaskHeads:
         pack = self._pack_plan(enc_dep, sentlens_dep, enc_tag, sentlens_tag)
         lens_d = as_sentlens(sentlens_dep, enc_dep.device)
         lens_t = as_sentlens(sentlens_tag, enc_tag.device)
-        # tagger chain on its own stream
+        # tagger chain on its own stream; up to 32 tags: the embedding folded into ner_tag_clf's columns, upos_clf inside the tail
+        t_emb, t_wne = (None, w.ner_w_tags) if w.ner_w_tags is not None and w.upos_clf_w.shape[0] <= 32 else (w.emb_ner, w.ner_w_emb)
+
         def run_tagger(after):
             s_tag.wait_event(after)
             for t in (enc_tag, lens_t):  # the caller may drop its batch while the side stream still reads it
@@ -754,12 +760,12 @@ class TaskHeads:
                     off_t, map_t = ops.pack_descriptor(lens_t, Lt, pack[1])
                     encp = ops.pack_rows(enc_tag.reshape(Bt * Lt, -1), map_t)
                     pos_p, ner_p, _ = ops.tagger_head(encp.view(1, pack[1], -1), off_t[Bt:], w.tag_Whn, w.tag_bhn,
-                                                      w.upos_clf_w, w.upos_clf_b, w.emb_ner, w.ner_w_emb, w.ner_b)
+                                                      w.upos_clf_w, w.upos_clf_b, t_emb, t_wne, w.ner_b)
                     tag = {"pos_pred": ops.unpack_rows(pos_p.view(-1), map_t, Bt * Lt).view(Bt, Lt),
                            "ner_logits": ops.unpack_rows(ner_p.view(pack[1], -1), map_t, Bt * Lt).view(Bt, Lt, -1)}
                 else:
                     pos_pred, ner_logits, _ = ops.tagger_head(enc_tag.contiguous(), lens_t, w.tag_Whn, w.tag_bhn,
-                                                              w.upos_clf_w, w.upos_clf_b, w.emb_ner, w.ner_w_emb, w.ner_b)
+                                                              w.upos_clf_w, w.upos_clf_b, t_emb, t_wne, w.ner_b)
                     tag = {"pos_pred": pos_pred, "ner_logits": ner_logits}
                 ner, _ = ops.crf_viterbi(tag["ner_logits"], w.trans, lens_t)
                 tag_done = torch.cuda.Event()

@@ -112,14 +112,18 @@ def pos_head(enc: Tensor, sentlens: Tensor, Whid: Tensor, bhid: Tensor, Wclf: Te
 
 
 @torch.library.custom_op("phonlp_amd::tagger_head", mutates_args=())
-def tagger_head(enc: Tensor, sentlens: Tensor, Whn: Tensor, bhn: Tensor, Wclf: Tensor, bclf: Tensor, emb: Tensor,
-                Wner_emb: Tensor, bner: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+def tagger_head(enc: Tensor, sentlens: Tensor, Whn: Tensor, bhn: Tensor, Wclf: Tensor, bclf: Tensor,
+                emb: Optional[Tensor], Wner_emb: Tensor, bner: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
     """Fused tagger head (ref annotate_model.py:132-150): enc [B,L,E] -> (pos_pred int32 [B,L], ner_logits [B,L,T],
-    upos_logits [B,L,U]); Whn / bhn / Wner_emb as HeadWeights packs them (include/phonlp_heads.h)."""
+    upos_logits [B,L,U]); Whn / bhn / Wner_emb as HeadWeights packs them (include/phonlp_heads.h).  emb=None (U <= 32):
+    Wner_emb is ner_tag_clf.weight[:, E:] @ emb^T [T, U] (the embedding folded at load), upos_clf runs inside the tail."""
     _need(enc, torch.float32, "enc")
     _need(sentlens, torch.int32, "sentlens")
     B, L, E = enc.shape
-    U, TE, T = Wclf.shape[0], emb.shape[1], Wner_emb.shape[0]
+    U, T = Wclf.shape[0], Wner_emb.shape[0]
+    TE = emb.shape[1] if emb is not None else U
+    if emb is None and Wner_emb.shape[1] != U:
+        raise ValueError("tagger_head: emb=None needs Wner_emb [T, U]")
     H = Whn.shape[0] - T
     dev = enc.device
     pos = torch.empty((B, L), dtype=torch.int32, device=dev)

@@ -872,6 +872,20 @@ def test_fused_tagger_head(dev, engine, B, L, E, TE, H, U, T):
     _near_tie_ok(pos.cpu(), ot["pos_pred"], ot["upos_logits"], 1e-5)
     live = torch.arange(L)[None, :] < lens[:, None]
     assert (ner.cpu()[~live] == 0).all() and (pos.cpu()[~live] == 0).all()
+    if U <= 32:
+        # emb=None: upos_emb_matrix_ner folded into ner_tag_clf's embedding columns at load, upos_clf inside the tail kernel
+        # (its 400-term sums in another order than the dense layer's); and a sentence's rows do not depend on the batch
+        pos2, ner2, logits2 = ops.tagger_head(enc.to(dev), lens_d, w.tag_Whn, w.tag_bhn, w.upos_clf_w, w.upos_clf_b, None,
+                                              w.ner_w_tags, w.ner_b)
+        _near_tie_ok(pos2.cpu(), ref["pos_pred"].cpu(), ref["upos_logits"].cpu(), 1e-5)
+        _close(logits2, ref["upos_logits"], rtol=1e-5, atol=2e-6)
+        _close(ner2, ref["ner_logits"], rtol=1e-5, atol=4e-6)
+        _close(ner2, ot["ner_logits"], rtol=1e-4, atol=1e-5)
+        assert (ner2.cpu()[~live] == 0).all() and (pos2.cpu()[~live] == 0).all() and (logits2.cpu()[~live] == 0).all()
+        nb = min(B, 2)
+        pos3, ner3, logits3 = ops.tagger_head(enc[:nb].to(dev).contiguous(), lens_d[:nb].contiguous(), w.tag_Whn, w.tag_bhn,
+                                              w.upos_clf_w, w.upos_clf_b, None, w.ner_w_tags, w.ner_b)
+        assert torch.equal(pos3, pos2[:nb]) and torch.equal(ner3, ner2[:nb]) and torch.equal(logits3, logits2[:nb])
 
 
 def test_streaming_batches_match_joined(dev):
