@@ -58,30 +58,15 @@ __global__ __launch_bounds__(256) void split_rows_kernel(SplitSet a, SplitSet b,
     const int row = ((int)blockIdx.x - (second ? nb1 : 0)) * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float *x = X + (long)row * ldx;
-    unsigned mx = 0;
-    for (int c = lane * 4; c < K; c += 256) {
-        const float4 v = *reinterpret_cast<const float4 *>(x + c);
+    unsigned char *out = planes + (long)row * pitch;
+    auto amax4 = [](unsigned mx, const float4 &v) {
         mx = max(mx, __float_as_uint(v.x) & 0x7FFFFFFFu);
         mx = max(mx, __float_as_uint(v.y) & 0x7FFFFFFFu);
         mx = max(mx, __float_as_uint(v.z) & 0x7FFFFFFFu);
-        mx = max(mx, __float_as_uint(v.w) & 0x7FFFFFFFu);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
-    int E = (int)(mx >> 23);  // biased exponent of the row maximum
-    E = E < 16 ? 16 : (E > 254 ? 254 : E);
-    const float scale = __uint_as_float((unsigned)(268 - E) << 23);  // 2^(14 - (E - 127)): maximum -> [2^14, 2^15)
-    if (lane == 0) inv_scale[row] = __uint_as_float((unsigned)(E - 14) << 23);
-    unsigned char *out = planes + (long)row * pitch;
-    for (int g = lane; g * 8 < K16; g += 64) {
-        float v[8];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int c = g * 8 + q * 4;
-            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (c < K) t = *reinterpret_cast<const float4 *>(x + c);
-            v[q * 4 + 0] = t.x; v[q * 4 + 1] = t.y; v[q * 4 + 2] = t.z; v[q * 4 + 3] = t.w;
-        }
+        return max(mx, __float_as_uint(v.w) & 0x7FFFFFFFu);
+    };
+    auto put = [&](int g, const float4 &t0, const float4 &t1, float scale) {
+        const float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
         f16x8 h, l;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -91,6 +76,43 @@ __global__ __launch_bounds__(256) void split_rows_kernel(SplitSet a, SplitSet b,
         }
         *reinterpret_cast<f16x8 *>(out + g * 32) = h;
         *reinterpret_cast<f16x8 *>(out + g * 32 + 16) = l;
+    };
+    auto scale_of = [&](unsigned mx) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
+        int E = (int)(mx >> 23);  // biased exponent of the row maximum
+        E = E < 16 ? 16 : (E > 254 ? 254 : E);
+        if (lane == 0) inv_scale[row] = __uint_as_float((unsigned)(E - 14) << 23);
+        return __uint_as_float((unsigned)(268 - E) << 23);  // 2^(14 - (E - 127)): maximum -> [2^14, 2^15)
+    };
+    constexpr int NG = 4;  // rows of up to 64 * NG groups of eight (K16 <= 2048) are read ONCE and kept in registers
+    if (K16 <= 512 * NG) {
+        float4 t[NG][2];
+        unsigned mx = 0;
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            const int c = (lane + 64 * j) * 8;
+            t[j][0] = make_float4(0.f, 0.f, 0.f, 0.f);
+            t[j][1] = t[j][0];
+            if (c < K) t[j][0] = *reinterpret_cast<const float4 *>(x + c);
+            if (c + 4 < K) t[j][1] = *reinterpret_cast<const float4 *>(x + c + 4);
+        }
+#pragma unroll
+        for (int j = 0; j < NG; ++j) mx = amax4(amax4(mx, t[j][0]), t[j][1]);
+        const float scale = scale_of(mx);
+#pragma unroll
+        for (int j = 0; j < NG; ++j)
+            if ((lane + 64 * j) * 8 < K16) put(lane + 64 * j, t[j][0], t[j][1], scale);
+        return;
+    }
+    unsigned mx = 0;
+    for (int c = lane * 4; c < K; c += 256) mx = amax4(mx, *reinterpret_cast<const float4 *>(x + c));
+    const float scale = scale_of(mx);
+    for (int g = lane; g * 8 < K16; g += 64) {
+        float4 t0 = make_float4(0.f, 0.f, 0.f, 0.f), t1 = t0;
+        if (g * 8 < K) t0 = *reinterpret_cast<const float4 *>(x + g * 8);
+        if (g * 8 + 4 < K) t1 = *reinterpret_cast<const float4 *>(x + g * 8 + 4);
+        put(g, t0, t1, scale);
     }
 }
 
