@@ -470,11 +470,21 @@ __global__ __launch_bounds__(256) void gather_heads_rows_kernel(const int32_t *h
     }
     __syncthreads();
     const int total = 32 * c4n;
-    for (int idx = tid; idx < total; idx += 256) {
-        const int w = idx / c4n, c4 = idx - w * c4n;
-        const int h = hr[w];
-        tile[w * pitch + c4] = h >= 0 ? *reinterpret_cast<const float4 *>(x2 + (long)h * ldx2 + 4 * c4)
-                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int idx0 = tid; idx0 < total; idx0 += 4 * 256) {  // four loads in flight per thread
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = idx0 + 256 * u;
+            const int w = idx < total ? idx / c4n : 0, c4 = idx - w * c4n;
+            const int h = idx < total ? hr[w] : -1;
+            v[u] = h >= 0 ? *reinterpret_cast<const float4 *>(x2 + (long)h * ldx2 + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = idx0 + 256 * u;
+            const int w = idx / c4n, c4 = idx - w * c4n;
+            if (idx < total) tile[w * pitch + c4] = v[u];
+        }
     }
     __syncthreads();
     for (int idx = tid; idx < total; idx += 256) {
@@ -497,7 +507,15 @@ __global__ __launch_bounds__(512) void label_reduce_kernel(const float *P, const
     if (live)
         for (int o = oq; o < O; o += 8) {
             float s = 0.f;
-            for (int t = 0; t < gpo; ++t) s += P[(long)(t * O + o) * M + m];
+            if (gpo <= 16) {  // a relation's shares in flight together, added in the same ascending order
+                float v[16];
+#pragma unroll
+                for (int t = 0; t < 16; ++t) v[t] = t < gpo ? P[(long)(t * O + o) * M + m] : 0.f;
+#pragma unroll
+                for (int t = 0; t < 16; ++t) s = t < gpo ? s + v[t] : s;
+            } else {
+                for (int t = 0; t < gpo; ++t) s += P[(long)(t * O + o) * M + m];
+            }
             if (s > bv) { bv = s; bo = o; }
         }
     sv[oq][lx] = bv;

@@ -1,0 +1,11 @@
+cd $GRAFT_REPO_ROOT
+run() {
+  PHONLP_LIB=$1 PHONLP_BENCH_OTHERS=0 timeout -k 10 200 python tools/ab_bench.py --no-cpu-baseline > gpurun_out/ab_tmp.json 2> gpurun_out/ab_tmp.err || { echo "FAILED: $1"; tail -3 gpurun_out/ab_tmp.err; return 1; }
+  python3 -c "
+import json,sys
+r=json.loads(open('gpurun_out/ab_tmp.json').read().strip().splitlines()[-1])
+k=r['kernels_ms']
+print('%-40s %.4f ms/step streaming %.4f | gather %.4f reduce %.4f split %.4f' % (sys.argv[1], r['ms_per_step'], r['streaming']['ms_per_step'], k['gather_heads_t'], k['label_reduce'], k['split_rows']))
+" "$1"
+}
+for i in 1 2; do run tools/libphonlp_heads_prev.so && run phonlp_amd/lib/libphonlp_heads.so || exit 1; done
