@@ -13,6 +13,55 @@ __device__ __forceinline__ float lane_bcast(float v, int src) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
 }
 
+// The trellis steps with the lane's column of the transition matrix in registers and the loop over the previous tag
+// unrolled (TP = T rounded up to 4; the columns beyond T hold -inf, which never wins a strict '>'): a step is TP readlane /
+// add / compare triples, and the next step's emission is read while this one is computed (the loop over p with an LDS read
+// per iteration cost ~1200 cycles a step at T = 9).  Same operations on the real tags in the same order: same bits.
+template <int TP>
+__device__ __forceinline__ float viterbi_steps(const float *sc, const float *tr, uint8_t *bp, float prev, int len, int T, int c,
+                                               int lane) {
+    float trc[TP];
+#pragma unroll
+    for (int p = 0; p < TP; ++p) trc[p] = p < T ? tr[p * T + c] : -INFINITY;
+    float em = len > 1 ? sc[T + c] : 0.f;
+    for (int t = 1; t < len; ++t) {
+        const float em_next = t + 1 < len ? sc[(t + 1) * T + c] : 0.f;
+        float bestv = lane_bcast(prev, 0) + trc[0];
+        int arg = 0;
+#pragma unroll
+        for (int p = 1; p < TP; ++p) {
+            const float v = lane_bcast(prev, p) + trc[p];
+            if (v > bestv) { bestv = v; arg = p; }  // strict: first maximum wins (np.argmax)
+        }
+        prev = em + bestv;
+        em = em_next;
+        if (lane < T) bp[t * T + lane] = (uint8_t)arg;
+    }
+    return prev;
+}
+
+// The forward recursion's steps in the same form (columns beyond T: -inf, i.e. exp(.) = 0 terms at the end of the sum).
+template <int TP>
+__device__ __forceinline__ float crf_forward_steps(const float *sc, const float *tr, const uint8_t *mk, float alpha, int len, int L,
+                                                   int T, int c) {
+    float trc[TP];
+#pragma unroll
+    for (int p = 0; p < TP; ++p) trc[p] = p < T ? tr[p * T + c] : -INFINITY;
+    for (int t = 1; t < L; ++t) {
+        const bool pad = (t >= len) || (mk && __builtin_amdgcn_readfirstlane((int)mk[t]) != 0);
+        if (pad) continue;  // ref :95-98 keeps the old alphas on padding
+        float v[TP];
+        float m = -INFINITY;
+#pragma unroll
+        for (int p = 0; p < TP; ++p) { v[p] = lane_bcast(alpha, p) + trc[p]; m = fmaxf(m, v[p]); }
+        float s = 0.f;
+#pragma unroll
+        for (int p = 0; p < TP; ++p) s += expf(v[p] - m);
+        alpha = sc[t * T + c] + (m + logf(s));
+    }
+    return alpha;
+}
+
 // Dynamic LDS: trans[T*T] | per wave { emissions[L*T] f32 | backptr[L*T] u8 (Viterbi only) }
 __global__ __launch_bounds__(256) void viterbi_kernel(const float *logits, const float *trans, const int32_t *sentlens,
                                                       int B, int L, int T, int wave_floats, int32_t *tags,
@@ -42,15 +91,22 @@ __global__ __launch_bounds__(256) void viterbi_kernel(const float *logits, const
 
     const int c = lane < T ? lane : T - 1;  // idle lanes shadow the last tag, results unused
     float prev = sc[c];
-    for (int t = 1; t < len; ++t) {
-        float bestv = lane_bcast(prev, 0) + tr[c];
-        int arg = 0;
-        for (int p = 1; p < T; ++p) {
-            const float v = lane_bcast(prev, p) + tr[p * T + c];
-            if (v > bestv) { bestv = v; arg = p; }  // strict: first maximum wins (np.argmax)
+    if (T <= 16) {
+        if (T <= 4) prev = viterbi_steps<4>(sc, tr, bp, prev, len, T, c, lane);
+        else if (T <= 8) prev = viterbi_steps<8>(sc, tr, bp, prev, len, T, c, lane);
+        else if (T <= 12) prev = viterbi_steps<12>(sc, tr, bp, prev, len, T, c, lane);
+        else prev = viterbi_steps<16>(sc, tr, bp, prev, len, T, c, lane);
+    } else {
+        for (int t = 1; t < len; ++t) {
+            float bestv = lane_bcast(prev, 0) + tr[c];
+            int arg = 0;
+            for (int p = 1; p < T; ++p) {
+                const float v = lane_bcast(prev, p) + tr[p * T + c];
+                if (v > bestv) { bestv = v; arg = p; }  // strict: first maximum wins (np.argmax)
+            }
+            prev = sc[t * T + c] + bestv;
+            if (lane < T) bp[t * T + lane] = (uint8_t)arg;
         }
-        prev = sc[t * T + c] + bestv;
-        if (lane < T) bp[t * T + lane] = (uint8_t)arg;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     // arg-max over the last trellis row, lowest index on ties
@@ -94,14 +150,21 @@ __global__ __launch_bounds__(256) void crf_forward_kernel(const float *logits, c
 
     const int c = lane < T ? lane : T - 1;
     float alpha = sc[c];
-    for (int t = 1; t < L; ++t) {
-        const bool pad = (t >= len) || (mk && __builtin_amdgcn_readfirstlane((int)mk[t]) != 0);
-        if (pad) continue;  // ref :95-98 keeps the old alphas on padding
-        float m = -INFINITY;
-        for (int p = 0; p < T; ++p) m = fmaxf(m, lane_bcast(alpha, p) + tr[p * T + c]);
-        float s = 0.f;
-        for (int p = 0; p < T; ++p) s += expf((lane_bcast(alpha, p) + tr[p * T + c]) - m);
-        alpha = sc[t * T + c] + (m + logf(s));
+    if (T <= 16) {
+        if (T <= 4) alpha = crf_forward_steps<4>(sc, tr, mk, alpha, len, L, T, c);
+        else if (T <= 8) alpha = crf_forward_steps<8>(sc, tr, mk, alpha, len, L, T, c);
+        else if (T <= 12) alpha = crf_forward_steps<12>(sc, tr, mk, alpha, len, L, T, c);
+        else alpha = crf_forward_steps<16>(sc, tr, mk, alpha, len, L, T, c);
+    } else {
+        for (int t = 1; t < L; ++t) {
+            const bool pad = (t >= len) || (mk && __builtin_amdgcn_readfirstlane((int)mk[t]) != 0);
+            if (pad) continue;  // ref :95-98 keeps the old alphas on padding
+            float m = -INFINITY;
+            for (int p = 0; p < T; ++p) m = fmaxf(m, lane_bcast(alpha, p) + tr[p * T + c]);
+            float s = 0.f;
+            for (int p = 0; p < T; ++p) s += expf((lane_bcast(alpha, p) + tr[p * T + c]) - m);
+            alpha = sc[t * T + c] + (m + logf(s));
+        }
     }
     float m = lane < T ? alpha : -INFINITY;
 #pragma unroll
