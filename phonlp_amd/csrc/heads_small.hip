@@ -310,7 +310,7 @@ __device__ __forceinline__ void pos_tile_softmax(const pf32x16 &acc, const float
         for (int q = 0; q < 4; ++q) {
             const int u0 = 8 * q + 4 * hf;
             float *dst = logits_out + (long)tok * U + u0;
-            if (u0 + 3 < U && !(U & 3)) {
+            if (u0 + 3 < U && !(U & 3) && !((uintptr_t)logits_out & 15)) {
                 *reinterpret_cast<float4 *>(dst) = live ? make_float4(lg[4 * q], lg[4 * q + 1], lg[4 * q + 2], lg[4 * q + 3])
                                                         : make_float4(0.f, 0.f, 0.f, 0.f);
             } else {
@@ -587,6 +587,8 @@ static int pos_head_impl(const float *enc, int ld_enc, const int32_t *sentlens, 
     // emb == NULL: the embedding columns hold the tag probabilities themselves (pos_clf_tail_kernel: upos_clf inside the tail)
     if (!emb && (U > 32 || TE < U || TE > 32))
         return fail(PHONLP_ERR_UNSUPPORTED, "pos_head: emb == NULL (probabilities as the embedding) needs U <= TE <= 32");
+    if (!emb && (((uintptr_t)Wclf | (uintptr_t)ws | (uintptr_t)enc) & 15))
+        return fail(PHONLP_ERR_SHAPE, "pos_head: emb == NULL needs enc, Wclf and the workspace 16-byte aligned");
     if ((E & 3) || (H & 3) || ((E + TE) & 3) || (ld_enc & 3) || ((uintptr_t)feat & 15) || ((uintptr_t)feat_planes & 15))
         return fail(PHONLP_ERR_SHAPE, "pos_head: E, H, E+TE, ld_enc must be multiples of 4 and feat 16-byte aligned");
     if ((feat_planes != nullptr) != (feat_inv_scale != nullptr))
@@ -680,6 +682,8 @@ extern "C" int phonlp_tagger_head(const float *enc, int ld_enc, const int32_t *s
     if (U > 64 || U <= 0) return fail(PHONLP_ERR_UNSUPPORTED, "tagger_head: needs 1 <= U <= 64 (one lane per tag)");
     if (!emb && (U > 32 || TE != U || (3 * 1024 + (size_t)U * T) * sizeof(float) > 64 * 1024))
         return fail(PHONLP_ERR_UNSUPPORTED, "tagger_head: emb == NULL (identity embedding, Wner_emb [T, U]) needs TE == U <= 32");
+    if (!emb && (((uintptr_t)Wclf | (uintptr_t)ws) & 15))
+        return fail(PHONLP_ERR_SHAPE, "tagger_head: emb == NULL needs Wclf and the workspace 16-byte aligned");
     if ((E & 3) || (H & 3) || (ld_enc & 3)) return fail(PHONLP_ERR_SHAPE, "tagger_head: E, H, ld_enc must be multiples of 4");
     if (!ws || ws_bytes < phonlp_tagger_head_ws_bytes(B, L, E, H, U, TE, T))
         return fail(PHONLP_ERR_WORKSPACE, "tagger_head: workspace too small");

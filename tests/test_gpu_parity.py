@@ -846,6 +846,26 @@ def test_pos_head_probs_fused(dev, engine, B, L, E, H, U, enc_scale):
     assert torch.equal(log2, log1[:nb])
 
 
+def test_probs_forms_refuse_what_they_cannot_do(dev):
+    """The emb=None forms hold a token's tags in one 32 x 32 accumulator tile: more than 32 tags are refused with an error
+    (the caller then passes an embedding matrix, the two-launch form), never computed wrongly."""
+    from phonlp_amd import HeadWeights, ops
+    from phonlp_amd import synthetic as S
+    E, TE, H, U, T = 64, 12, 24, 40, 5
+    w = HeadWeights.from_state_dict(S.make_state_dict(E, TE, H, U, 5, T, seed=1), dev)
+    enc = torch.randn(2, 9, E, device=dev)
+    lens = torch.tensor([9, 4], dtype=torch.int32, device=dev)
+    with pytest.raises(Exception, match="emb == NULL"):
+        ops.pos_head_split(enc, lens, w.upos_hid_w, w.upos_hid_b, w.upos_clf_w, w.upos_clf_b, None, False)
+    with pytest.raises(Exception, match="emb == NULL"):
+        ops.tagger_head(enc, lens, w.tag_Whn, w.tag_bhn, w.upos_clf_w, w.upos_clf_b, None, w.ner_w_tags, w.ner_b)
+    # and the whole step still runs at that size (annotate_batch picks the two-launch forms)
+    from phonlp_amd import TaskHeads
+    out = TaskHeads(w).annotate_batch(torch.randn(2, 10, E, device=dev), [10, 5], enc, [9, 4])
+    torch.cuda.synchronize()
+    assert int((out["mst_status"] != 0).sum()) == 0
+
+
 @pytest.mark.parametrize("B,L,E,TE,H,U,T", [(7, 33, 64, 12, 24, 7, 5), (5, 19, 24, 8, 16, 7, 3), (2, 4, 20, 4, 8, 3, 70),
                                              (16, 127, 768, 100, 400, 24, 9)])
 def test_fused_tagger_head(dev, engine, B, L, E, TE, H, U, T):
