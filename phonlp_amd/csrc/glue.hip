@@ -69,59 +69,91 @@ __global__ __launch_bounds__(256) void eval_counts_kernel(const int32_t *pos, co
 // Entity-level NER counts (ref models/ner/scorer.py:13-57 score_by_entity over ner/utils.py:85-128
 // decode_from_bioes): counts[0..2] += {predicted entities also in gold, predicted entities, gold entities}.
 // tag_kind[t]: 0 'O', 1 'B-', 2 'I-', 3 'E-', 4 'S-', anything else = a tag the decoder ignores (<PAD>, <UNK>, ...);
-// tag_type[t]: id of the type string after the prefix.  One wavefront per sentence: the tags are staged in LDS,
-// lane 0 replays the reference's state machine (an entity = first index, last index, type of its LAST tag) over
-// gold -- recording (end, type) at the entity's start index, which is unique per entity -- and then over the
-// prediction, looking each entity up at its start.
+// tag_type[t]: id of the type string after the prefix.  One wavefront per sentence, 64 positions at a time, a lane per
+// position.  The reference's state machine (an entity = first index, last index, type of its LAST tag) has only local
+// dependencies once the ignored tags are skipped: with p = the last decoded position before i,
+//   "an entity is open before i"  <=>  kind[p] is B or I;
+//   the open entity's start       =   the last position <= p that is a B, or an I / E with nothing open before it;
+//   i closes the open entity (start, p, type[p]) when it is an O, B or S (and the sentence's end closes one);
+//   an E emits (start or i itself, i, type[i]), an S emits (i, i, type[i]).
+// So a chunk needs two ballots (decoded positions, run starts), a few cross-lane reads, and the carry of the last decoded
+// position's kind / type / index / run start from the chunk before.  Gold entities are recorded at their start index --
+// unique per entity -- and the predicted ones looked up there.  (Round 2's form, lane 0 walking the sentence twice: 55 us
+// at B=256, L=127.)
 __global__ __launch_bounds__(64) void ner_entity_counts_kernel(const int32_t *pred, const int32_t *gold,
                                                                const int32_t *sentlens, const int32_t *tag_kind,
                                                                const int32_t *tag_type, int L, int T,
                                                                unsigned long long *counts) {
     extern __shared__ int sm[];
-    int *kp = sm, *kg = sm + L, *ge = sm + 2 * L, *gt = sm + 3 * L;  // packed (kind<<24 | type) per position; gold table
+    int *ge = sm, *gt = sm + L;  // gold entity that starts at a position: its last index and type (-1: none)
     const int b = blockIdx.x, lane = threadIdx.x;
     int len = sentlens[b];
     if (len > L) len = L;
-    for (int i = lane; i < len; i += 64) {
-        const int tp = pred[(long)b * L + i], tg = gold[(long)b * L + i];
-        kp[i] = (tp >= 0 && tp < T) ? (tag_kind[tp] << 24) | (tag_type[tp] & 0xFFFFFF) : (5 << 24);
-        kg[i] = (tg >= 0 && tg < T) ? (tag_kind[tg] << 24) | (tag_type[tg] & 0xFFFFFF) : (5 << 24);
-        ge[i] = -1;
-        gt[i] = -1;
-    }
-    __syncthreads();
-    if (lane != 0) return;
-    unsigned long long n_correct = 0, n_pred = 0, n_gold = 0;
-    auto scan = [&](const int *tags, auto emit) {
-        int cnt = 0, start = 0, last = 0, ctype = -1;
-        for (int i = 0; i < len; ++i) {
-            const int kind = tags[i] >> 24, ty = tags[i] & 0xFFFFFF;
-            if (kind == 0) {  // O
-                if (cnt) emit(start, last, ctype);
-                cnt = 0;
-            } else if (kind == 1) {  // B-
-                if (cnt) emit(start, last, ctype);
-                cnt = 1; start = last = i; ctype = ty;
-            } else if (kind == 2) {  // I-
-                if (!cnt) start = i;
-                ++cnt; last = i; ctype = ty;
-            } else if (kind == 3) {  // E-
-                if (!cnt) start = i;
-                emit(start, i, ty);
-                cnt = 0;
-            } else if (kind == 4) {  // S-
-                if (cnt) emit(start, last, ctype);
-                emit(i, i, ty);
-                cnt = 0;
+    for (int i = lane; i < len; i += 64) { ge[i] = -1; gt[i] = -1; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const unsigned long long below = (1ull << lane) - 1ull, upto = below | (1ull << lane);
+    unsigned n_correct = 0, n_pred = 0, n_gold = 0;
+    for (int pass = 0; pass < 2; ++pass) {  // gold first (fills ge / gt), then the prediction
+        const int32_t *tags = (pass ? pred : gold) + (long)b * L;
+        int c_kind = 0, c_type = -1, c_pos = -1, c_start = -1;  // carry: the last decoded position so far (none: like an O)
+        for (int base = 0; base < len; base += 64) {
+            const int i = base + lane;
+            int kind = 5, ty = -1;
+            if (i < len) {
+                const int t = tags[i];
+                if (t >= 0 && t < T) { kind = tag_kind[t]; ty = tag_type[t] & 0xFFFFFF; }
+                if (kind < 0 || kind > 4) kind = 5;
+            }
+            const bool dec = kind <= 4;
+            const unsigned long long mdec = __ballot(dec);
+            // the decoded position before this one: in the chunk, or the carry
+            const unsigned long long pm = mdec & below;
+            const int pl = pm ? 63 - __builtin_clzll(pm) : 0;
+            const int pk_in = __shfl(kind, pl), pt_in = __shfl(ty, pl);
+            const int pkind = pm ? pk_in : c_kind, ptype = pm ? pt_in : c_type, ppos = pm ? base + pl : c_pos;
+            const bool open_before = pkind == 1 || pkind == 2;
+            const bool rs = dec && (kind == 1 || ((kind == 2 || kind == 3) && !open_before));  // a run starts here
+            const unsigned long long mrs = __ballot(rs);
+            const unsigned long long sm_ = mrs & upto;
+            const int start = sm_ ? base + 63 - __builtin_clzll(sm_) : c_start;  // of the run this position is in (B / I / E)
+            const int pstart_in = __shfl(start, pl);
+            const int pstart = pm ? pstart_in : c_start;  // of the entity open before this position
+            // emissions of this position: (a) it closes the open entity, (b) its own (E, S)
+            const bool ea = dec && open_before && (kind == 0 || kind == 1 || kind == 4);
+            const bool eb = kind == 3 || kind == 4;
+            const int b_start = kind == 4 ? i : start;
+            if (pass == 0) {
+                if (ea) { ge[pstart] = ppos; gt[pstart] = ptype; }
+                if (eb) { ge[b_start] = i; gt[b_start] = ty; }
+                n_gold += __popcll(__ballot(ea)) + __popcll(__ballot(eb));
+            } else {
+                const int ia = ea ? pstart : 0, ib = eb ? b_start : 0;  // (no read outside the tables where nothing is emitted)
+                const bool ca = ea && ge[ia] == ppos && gt[ia] == ptype;
+                const bool cb = eb && ge[ib] == i && gt[ib] == ty;
+                n_pred += __popcll(__ballot(ea)) + __popcll(__ballot(eb));
+                n_correct += __popcll(__ballot(ca)) + __popcll(__ballot(cb));
+            }
+            if (mdec) {  // carry: the chunk's last decoded position
+                const int ll = 63 - __builtin_clzll(mdec);
+                c_kind = __shfl(kind, ll); c_type = __shfl(ty, ll); c_pos = base + ll; c_start = __shfl(start, ll);
             }
         }
-        if (cnt) emit(start, last, ctype);
-    };
-    scan(kg, [&](int st, int en, int ty) { ge[st] = en; gt[st] = ty; ++n_gold; });
-    scan(kp, [&](int st, int en, int ty) { ++n_pred; n_correct += (ge[st] == en && gt[st] == ty); });
-    if (n_correct) atomicAdd(&counts[0], n_correct);
-    if (n_pred) atomicAdd(&counts[1], n_pred);
-    if (n_gold) atomicAdd(&counts[2], n_gold);
+        if (c_kind == 1 || c_kind == 2) {  // the sentence's end closes the open entity (wave-uniform)
+            if (pass == 0) {
+                if (lane == 0) { ge[c_start] = c_pos; gt[c_start] = c_type; }
+                ++n_gold;
+            } else {
+                ++n_pred;
+                n_correct += (ge[c_start] == c_pos && gt[c_start] == c_type) ? 1u : 0u;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    if (lane == 0) {
+        if (n_correct) atomicAdd(&counts[0], (unsigned long long)n_correct);
+        if (n_pred) atomicAdd(&counts[1], (unsigned long long)n_pred);
+        if (n_gold) atomicAdd(&counts[2], (unsigned long long)n_gold);
+    }
 }
 
 // Device-side unsort (ref annotate_model.py:270,277,287,291-293 / models/common/utils.py:189-195): the batch's rows go
@@ -283,7 +315,7 @@ extern "C" int phonlp_ner_entity_counts(const int32_t *pred, const int32_t *gold
         return fail(PHONLP_ERR_SHAPE, "ner_entity_counts: bad argument");
     if ((size_t)L * 4 * sizeof(int) > 64 * 1024) return fail(PHONLP_ERR_UNSUPPORTED, "ner_entity_counts: L > 4096");
     ProfScope ps("ner_entity_counts", as_stream(stream));
-    hipLaunchKernelGGL(ner_entity_counts_kernel, dim3(B), dim3(64), (size_t)L * 4 * sizeof(int), as_stream(stream), pred,
+    hipLaunchKernelGGL(ner_entity_counts_kernel, dim3(B), dim3(64), (size_t)L * 2 * sizeof(int), as_stream(stream), pred,
                        gold, sentlens, tag_kind, tag_type, L, T, (unsigned long long *)counts);
     return check_launch("ner_entity_counts_kernel");
 }

@@ -985,6 +985,20 @@ def test_ner_entity_counts(dev, golden):
     ps = [[vocab[t] for t in pred[b, :lens[b]].tolist()] for b in range(B)]
     gs = [[vocab[t] for t in gold[b, :lens[b]].tolist()] for b in range(B)]
     assert got == list(O.ner_entity_counts(ps, gs))
+    # long sentences (the kernel walks them 64 positions at a time, entities and ignored tags across the chunk borders),
+    # every tag equally likely, lengths on and around the borders
+    for seed, (B, L) in enumerate([(40, 300), (9, 64), (9, 65), (5, 129)]):
+        g = torch.Generator().manual_seed(100 + seed)
+        gold = torch.randint(0, len(vocab), (B, L), generator=g)
+        pred = torch.where(torch.rand(B, L, generator=g) < 0.3, torch.randint(0, len(vocab), (B, L), generator=g), gold)
+        lens = torch.randint(1, L + 1, (B,), generator=g)
+        lens[0] = L
+        lens[1] = min(L, 64)
+        got = ops.ner_entity_counts(pred.to(torch.int32).to(dev), gold.to(torch.int32).to(dev), lens.to(torch.int32).to(dev),
+                                    kind, typ).cpu().tolist()
+        ps = [[vocab[t] for t in pred[b, :lens[b]].tolist()] for b in range(B)]
+        gs = [[vocab[t] for t in gold[b, :lens[b]].tolist()] for b in range(B)]
+        assert got == list(O.ner_entity_counts(ps, gs)), (B, L)
 
 
 def test_folded_dep_hid_matches_unfolded(dev, engine):
