@@ -801,7 +801,8 @@ def _image_rows(planes, inv, K):
 
 @pytest.mark.parametrize("B,L,E,H,U,enc_scale", [(7, 33, 64, 24, 7, 1.0), (9, 21, 64, 24, 7, 1e-3), (5, 19, 24, 16, 7, 1.0),
                                                   (3, 9, 20, 8, 3, 1.0), (4, 37, 64, 44, 32, 1.0), (6, 50, 64, 100, 17, 0.05),
-                                                  (16, 128, 768, 400, 24, 1.0), (1, 32, 768, 400, 24, 1.0)])
+                                                  (16, 128, 768, 400, 24, 1.0), (1, 32, 768, 400, 24, 1.0),
+                                                  (2, 5, 8, 4, 1, 1.0), (3, 70, 16, 12, 5, 1e-6)])
 def test_pos_head_probs_fused(dev, engine, B, L, E, H, U, enc_scale):
     """pos_head_split(emb=None) -- upos_clf inside the tail kernel, the tag probabilities where the embedding was -- against
     the two-launch form with emb = eye(U, Up): logits to fp32 rounding (another summation order), POS ids equal except
