@@ -919,9 +919,9 @@ class TaskHeads:
 
 
 class CapturedStep:
-    """`TaskHeads.annotate_batch` at ONE shape as a HIP graph: the step's 21 launches on three streams become one
+    """`TaskHeads.annotate_batch` at ONE shape as a HIP graph: the step's 19 launches on three streams become one
     `hipGraphLaunch`, so a loop that calls the heads at a fixed (bucketed) shape pays one launch per batch (B=1, L=32:
-    0.21 against 0.37 ms; B=32, L=64: 0.42 against 0.50; bench.py other_configs, tools/graph_probe.py).
+    0.18 against 0.33 ms; B=32, L=64: 0.40 against 0.47; bench.py other_configs, tools/graph_probe.py).
 
     The graph reads the STATIC input tensors below and writes the static tensors of `out`; the caller copies a batch in
     (`enc_dep.copy_(...)`, `lens_dep.copy_(...)`, ... on the replay stream), calls `replay()`, and reads `out`
