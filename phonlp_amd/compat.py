@@ -233,8 +233,18 @@ def _annotate(self, text=None, input_file=None, output_file=None, batch_size=1, 
     # Corpus-level result tables on the device: every batch scatters its rows to the sentences' places in the input
     # (the chunk sort and the batch sort composed on the host, ref :270,277,287,291-293), so the whole corpus comes
     # back in ONE device->host copy and the MST status is checked once, not per batch.
-    n, wmax = len(data), max(len(s_) for s_ in data)
-    table = torch.zeros((4, n, wmax), dtype=torch.int32, device=dev)  # pos, ner, head, rel
+    # The tables are kept per LENGTH CLASS (sentence lengths rounded up to a power of two, 8 at least): a corpus's one
+    # very long sentence sizes its own small table, not every sentence's row (the reference keeps ragged host lists); at
+    # most twice the words of the corpus in all.  slot[k] = (class, row) of sentence k.
+    n = len(data)
+    width = [max(8, 1 << max(len(s_) - 1, 0).bit_length()) for s_ in data]
+    classes = sorted(set(width))
+    rows_in = {c: 0 for c in classes}
+    slot = []
+    for c in width:
+        slot.append((c, rows_in[c]))
+        rows_in[c] += 1
+    tables = {c: torch.zeros((4, rows_in[c], c), dtype=torch.int32, device=dev) for c in classes}  # pos, ner, head, rel
     mst_failures = torch.zeros(1, dtype=torch.int32, device=dev)
     chunk_order = self.data_orig_idx
     start = 0
@@ -244,13 +254,30 @@ def _annotate(self, text=None, input_file=None, output_file=None, batch_size=1, 
             tok1, fsw1, _, _, oidx1, lens1 = self.get_batch(i, parser_batches)
             assert list(oidx) == list(oidx1), "tagger and parser batches must share their sort"
             out = heads_.annotate_batch(_encode(self, tok1, fsw1), lens1, _encode(self, tok, fsw), lens)
-            dest = torch.tensor([chunk_order[start + k] for k in oidx], dtype=torch.int32).to(dev, non_blocking=True)
-            ops.scatter_rows(out["pos"], 0, dest, table[0])
-            ops.scatter_rows(out["ner"], 0, dest, table[1])
-            ops.scatter_rows(out["heads"], 1, dest, table[2], out["mst_status"], mst_failures)
-            ops.scatter_rows(out["rels"], 1, dest, table[3])
+            sent = [chunk_order[start + k] for k in oidx]
+            counted = False
+            for c in sorted({slot[k][0] for k in sent}):  # a batch is sorted by length: one class, seldom two
+                dest = torch.tensor([slot[k][1] if slot[k][0] == c else -1 for k in sent],
+                                    dtype=torch.int32).to(dev, non_blocking=True)
+                table = tables[c]
+                ops.scatter_rows(out["pos"], 0, dest, table[0])
+                ops.scatter_rows(out["ner"], 0, dest, table[1])
+                if counted:
+                    ops.scatter_rows(out["heads"], 1, dest, table[2])
+                else:  # (the status count covers the whole batch: once)
+                    ops.scatter_rows(out["heads"], 1, dest, table[2], out["mst_status"], mst_failures)
+                    counted = True
+                ops.scatter_rows(out["rels"], 1, dest, table[3])
             start += len(lens)
-    host = table.cpu().numpy()
+    host_tables = {c: t.cpu().numpy() for c, t in tables.items()}
+
+    class _Rows:  # host[f, k, :len] of the old dense table, read through the sentence's slot
+        def __getitem__(self, key):
+            f, k, cols = key
+            c, r = slot[k]
+            return host_tables[c][f, r, cols]
+
+    host = _Rows()
     if int(mst_failures.item()):
         raise AssertionError("chuliu_edmonds_one_root: no finite single-root tree (reference asserts here)")
     pos_all = [[[u] for u in self.vocab["upos"].unmap(host[0, k, :len(s_)])] for k, s_ in enumerate(data)]
