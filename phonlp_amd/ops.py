@@ -94,12 +94,14 @@ def pack_scorer(W1: Tensor, b1: Tensor, W2: Tensor, b2: Tensor, Wbil: Tensor) ->
 
 @torch.library.custom_op("phonlp_amd::pos_head", mutates_args=())
 def pos_head(enc: Tensor, sentlens: Tensor, Whid: Tensor, bhid: Tensor, Wclf: Tensor, bclf: Tensor,
-             emb: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
-    """enc [B,L,E] -> (feat [B,L,E+TE], pos_pred int32 [B,L], upos_logits [B,L,U])."""
+             emb: Optional[Tensor]) -> Tuple[Tensor, Tensor, Tensor]:
+    """enc [B,L,E] -> (feat [B,L,E+TE], pos_pred int32 [B,L], upos_logits [B,L,U]).  emb=None (U <= 32): the embedding
+    columns hold the tag probabilities themselves, TE = U rounded up to 4."""
     _need(enc, torch.float32, "enc")
     _need(sentlens, torch.int32, "sentlens")
     B, L, E = enc.shape
-    H, U, TE = Whid.shape[0], Wclf.shape[0], emb.shape[1]
+    H, U = Whid.shape[0], Wclf.shape[0]
+    TE = emb.shape[1] if emb is not None else (U + 3) // 4 * 4
     dev = enc.device
     feat = torch.empty((B, L, E + TE), dtype=torch.float32, device=dev)
     pos = torch.empty((B, L), dtype=torch.int32, device=dev)
@@ -965,7 +967,8 @@ def _(W1, b1, W2, b2, Wbil):
 @pos_head.register_fake
 def _(enc, sentlens, Whid, bhid, Wclf, bclf, emb):
     B, L, E = enc.shape
-    return (enc.new_empty((B, L, E + emb.shape[1])), enc.new_empty((B, L), dtype=_I32),
+    TE = emb.shape[1] if emb is not None else (Wclf.shape[0] + 3) // 4 * 4
+    return (enc.new_empty((B, L, E + TE)), enc.new_empty((B, L), dtype=_I32),
             enc.new_empty((B, L, Wclf.shape[0])))
 
 

@@ -839,6 +839,12 @@ def test_pos_head_probs_fused(dev, engine, B, L, E, H, U, enc_scale):
             # the image is split_rows of the fp32 rows, bit for bit
             pf, iv = ops.split_rows(feat1.view(B * L, E + Up))
             assert torch.equal(pf.cpu()[live], p1.cpu()[live]) and torch.equal(iv.cpu()[live], i1.cpu()[live])
+    # the fp32 entry point (phonlp_pos_head) in the same form: the rows the split form wrote beside its image
+    feat3, pos3, log3 = ops.pos_head(enc, lens_d, w.upos_hid_w, w.upos_hid_b, w.upos_clf_w, w.upos_clf_b, None)
+    if ops.get_gemm_engine() == 2 and E % 8 == 0:  # (other engines: upos_hid itself runs on another kernel in the two entry points)
+        assert torch.equal(feat3, feat1) and torch.equal(pos3, pos1) and torch.equal(log3, log1)
+    else:
+        _close(feat3, feat1, rtol=1e-5, atol=2e-6)
     # sub-batch identity: the first two sentences alone give the same bits
     nb = min(B, 2)
     p2, i2, pos2, log2, _ = ops.pos_head_split(enc[:nb].contiguous(), lens_d[:nb].contiguous(), w.upos_hid_w, w.upos_hid_b,
