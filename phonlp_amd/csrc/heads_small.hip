@@ -124,11 +124,14 @@ __global__ __launch_bounds__(256) void pos_tail_kernel(const float *enc, long ld
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     p = p / s;
     unsigned mx = 0;
-    for (int d = lane; d < TE; d += 64) {
+    for (int d0 = 0; d0 < TE; d0 += 64) {  // every lane runs the loop: the broadcasts read lanes that would otherwise be inactive (TE < U)
+        const int d = d0 + lane;
         float acc = 0.f;
-        for (int u = 0; u < U; ++u) acc += __shfl(p, u) * emb[u * TE + d];
-        row[E + d] = acc;
-        mx = max(mx, __float_as_uint(acc) & 0x7FFFFFFFu);
+        for (int u = 0; u < U; ++u) acc += __shfl(p, u) * (d < TE ? emb[u * TE + d] : 0.f);
+        if (d < TE) {
+            row[E + d] = acc;
+            mx = max(mx, __float_as_uint(acc) & 0x7FFFFFFFu);
+        }
     }
     for (int c = D + lane; c < K16; c += 64) row[c] = 0.f;
     bool fast = prow && presplit;  // wave-uniform
@@ -445,10 +448,11 @@ __global__ __launch_bounds__(256) void tagger_tail_kernel(const float *hid, long
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     p = p / s;
-    for (int d = lane; d < TE; d += 64) {
+    for (int d0 = 0; d0 < TE; d0 += 64) {  // every lane runs the loop: the broadcasts read lanes that would otherwise be inactive (TE < U)
+        const int d = d0 + lane;
         float acc = 0.f;
-        for (int u = 0; u < U; ++u) acc += __shfl(p, u) * emb[u * TE + d];
-        e[d] = acc;
+        for (int u = 0; u < U; ++u) acc += __shfl(p, u) * (d < TE ? emb[u * TE + d] : 0.f);
+        if (d < TE) e[d] = acc;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     // e . Wne[t]: G = 64 / T lanes per tag, lane (t, g) sums the d = g (mod G) terms; the G shares of a tag are added in

@@ -760,7 +760,7 @@ def test_label_rows4_pair_matches_row_major(dev, B, L, H, O):
 
 @pytest.mark.parametrize("B,L,E,TE,H,U,emb_scale", [(7, 33, 64, 12, 24, 7, 1.0), (7, 33, 64, 12, 24, 7, 4.0),
                                                      (9, 21, 64, 12, 24, 7, 50.0), (5, 19, 24, 8, 16, 7, 1.0),
-                                                     (16, 128, 768, 100, 400, 24, 1.0)])
+                                                     (16, 128, 768, 100, 400, 24, 1.0), (4, 21, 64, 4, 24, 17, 1.0)])
 def test_pos_head_split_image(dev, B, L, E, TE, H, U, emb_scale):
     """pos_head_split = pos_head followed by split_rows(feat), bit for bit on the live rows (padded rows: zero planes),
     with or without the fp32 feat output.  Under engine 2 the enc columns of the image are written before the
@@ -777,6 +777,11 @@ def test_pos_head_split_image(dev, B, L, E, TE, H, U, emb_scale):
     lens[0] = L
     lens_d = lens.to(dev)
     feat0, pos0, log0 = ops.pos_head(enc, lens_d, w.upos_hid_w, w.upos_hid_b, w.upos_clf_w, w.upos_clf_b, w.emb_dep)
+    # the soft POS embedding itself against a torch product (fewer embedding columns than tags -- the last case -- once left
+    # the tail kernel's cross-lane broadcasts reading inactive lanes: found by tests/fuzz_step.py)
+    want_emb = torch.softmax(log0.double(), -1) @ w.emb_dep.double()
+    live3 = (torch.arange(L, device=dev)[None, :] < lens_d[:, None])
+    _close(feat0[..., E:][live3], want_emb.float()[live3], rtol=1e-5, atol=1e-6)
     p0, i0 = ops.split_rows(feat0.view(B * L, E + TE))
     live = (torch.arange(L)[None, :] < lens[:, None]).reshape(-1)
     for want_feat in (True, False):
@@ -874,7 +879,7 @@ def test_probs_forms_refuse_what_they_cannot_do(dev):
 
 
 @pytest.mark.parametrize("B,L,E,TE,H,U,T", [(7, 33, 64, 12, 24, 7, 5), (5, 19, 24, 8, 16, 7, 3), (2, 4, 20, 4, 8, 3, 70),
-                                             (16, 127, 768, 100, 400, 24, 9)])
+                                             (16, 127, 768, 100, 400, 24, 9), (6, 40, 64, 4, 24, 17, 3)])
 def test_fused_tagger_head(dev, engine, B, L, E, TE, H, U, T):
     """ops.tagger_head (upos_hid and the enc columns of ner_tag_clf in one GEMM, embedding columns added in the tail,
     feat never formed) against pos_head + ner_emission and against the oracle (ref annotate_model.py:132-150):
