@@ -12,12 +12,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import heads_oracle as O  # noqa: E402  (a checker: this file lives under tests/ and is run by hand, pytest does not collect it)
 from oracle import c_oracle as C  # noqa: E402
-from phonlp_amd import HeadWeights, TaskHeads  # noqa: E402
+from phonlp_amd import HeadWeights, TaskHeads, ops  # noqa: E402
 from phonlp_amd import synthetic as S  # noqa: E402
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 dev = torch.device("cuda:0")
+# FUZZ_MODE: letters l = every fourth case a long sentence batch (129..520 words), e = a random matrix engine per case,
+# f = random linearization / distance flags, s = every other case in the streaming form (join=False)
+MODE = os.environ.get("FUZZ_MODE", "")
+LONG, ENGINES, FLAGS, STREAM = "l" in MODE, "e" in MODE, "f" in MODE, "s" in MODE
 bad = 0
 for case in range(n_cases):
     E = int(rng.choice([16, 24, 40, 64]))
@@ -29,15 +33,22 @@ for case in range(n_cases):
     B = int(rng.integers(1, 41))
     L = int(rng.integers(2, 141))
     ragged = bool(rng.integers(0, 2))
+    if LONG and case % 4 == 0:  # long sentences: the arc kernel's LONG form, the round-based decode in global memory, unfused labels
+        B, L = int(rng.integers(1, 7)), int(rng.integers(129, 521))
+    engine = int(rng.integers(0, 3)) if ENGINES else 2
+    lin, dist = (bool(rng.integers(0, 2)), bool(rng.integers(0, 2))) if FLAGS else (True, True)
+    ops.set_gemm_engine(engine)
     sd = S.make_state_dict(E, TE, H, U, Orel, T, seed=1000 + case)
     enc_dep, enc_tag = S.make_encoder_outputs(B, L, E, seed=2000 + case)
     lens1 = sorted((int(x) for x in rng.integers(2, L + 1, B)), reverse=True) if ragged else [L] * B
     lens1[0] = L
     lens = [l - 1 for l in lens1]
-    heads = TaskHeads(HeadWeights.from_state_dict(sd, dev))
-    out = heads.annotate_batch(enc_dep.to(dev), lens1, enc_tag.to(dev), lens)
+    heads = TaskHeads(HeadWeights.from_state_dict(sd, dev, linearization=lin, distance=dist))
+    join = not (STREAM and case % 2)
+    out = heads.annotate_batch(enc_dep.to(dev), lens1 if case % 3 else torch.tensor(lens1, dtype=torch.int32, device=dev),
+                               enc_tag.to(dev), lens if case % 3 else torch.tensor(lens, dtype=torch.int32, device=dev), join=join)
     torch.cuda.synchronize()
-    od = O.dep_heads(enc_dep, lens1, sd)
+    od = O.dep_heads(enc_dep, lens1, sd, linearization=lin, distance=dist)
     ot = O.tagger_heads(enc_tag, lens, sd)
     wh, ws = C.mst_batch(od["arc_logp"].numpy(), lens1)
     gh, gs = C.mst_batch(out["arc_logp"].cpu().numpy(), lens1)  # the decoder alone, on the GPU's own scores: bit-exact
@@ -60,7 +71,6 @@ for case in range(n_cases):
                     d_ner -= int((gt[b] != wt[b]).sum())
     d_pos = int((out["pos"].cpu().numpy() != ot["pos_pred"].numpy()).sum())
     # the reference-shaped / two-launch forms of the same heads (an embedding matrix passed in): scores against the oracle
-    from phonlp_amd import ops
     w = heads.w
     ld_t = torch.tensor(lens, dtype=torch.int32, device=dev)
     tg = heads.tagger(enc_tag.to(dev), lens)
@@ -77,6 +87,6 @@ for case in range(n_cases):
     arc_err = float((out["arc_logp"].cpu() - od["arc_logp"])[fin].abs().max())  # (padded dependents are not scored)
     flag = "" if dec_ok and scores_ok and not (d_heads or d_rels or d_ner or d_pos) else "  <-- look"
     bad += (not dec_ok) + (not scores_ok) + d_heads + d_rels + d_ner + d_pos
-    print(f"case {case:3d} E={E} TE={TE} H={H} U={U} O={Orel} T={T} B={B} L={L} ragged={int(ragged)}: decoder_exact={dec_ok} "
+    print(f"case {case:3d} eng={engine} lin={int(lin)} dist={int(dist)} join={int(join)} E={E} TE={TE} H={H} U={U} O={Orel} T={T} B={B} L={L} ragged={int(ragged)}: decoder_exact={dec_ok} "
           f"diff heads {d_heads} rels {d_rels} ner {d_ner} pos {d_pos}; max |arc_logp - oracle| {arc_err:.2e}; two-launch forms: ner {e_ner:.1e} arc {e_arc2:.1e}{flag}", flush=True)
 print("total differing ids (and inexact decodes):", bad)
