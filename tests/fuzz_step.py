@@ -76,17 +76,24 @@ for case in range(n_cases):
     tg = heads.tagger(enc_tag.to(dev), lens)
     _, ner2, log2 = ops.tagger_head(enc_tag.to(dev), ld_t, w.tag_Whn, w.tag_bhn, w.upos_clf_w, w.upos_clf_b, w.emb_ner,
                                     w.ner_w_emb, w.ner_b)
-    dp = heads.parser(enc_dep.to(dev), lens1)
+    dp = heads.parser(enc_dep.to(dev), lens1, want_label_scores=True)  # the dense label tensor (B x L x O x L in memory)
     live_t = torch.arange(L - 1)[None, :] < torch.tensor(lens)[:, None]
     live_d = torch.arange(L)[None, :] < torch.tensor(lens1)[:, None]
     e_ner = max(float((tg["ner_logits"].cpu() - ot["ner_logits"])[live_t].abs().max()) if live_t.any() else 0.0,
                 float((ner2.cpu() - ot["ner_logits"])[live_t].abs().max()) if live_t.any() else 0.0)
     fin = torch.isfinite(od["arc_logp"]) & live_d[:, :, None]
     e_arc2 = float((dp["arc_logp"].cpu() - od["arc_logp"])[fin].abs().max())
-    scores_ok = e_ner < 2e-5 and e_arc2 < 2e-3
+    live_c = (live_d[:, :, None] & live_d[:, None, :])  # live (dependent, head) cells
+    ls_g, ls_o = dp["label_scores"].permute(0, 1, 3, 2).cpu(), od["label_scores"]
+    e_lab = float((ls_g - ls_o)[live_c].abs().max()) / (float(ls_o[live_c].abs().max()) + 1e-12)
+    am_g, am_o = dp["label_argmax"].cpu(), od["label_argmax"]
+    top = ls_o.max(-1)[0]
+    at = torch.gather(ls_o, -1, am_g.long().unsqueeze(-1)).squeeze(-1)
+    lab_flip_bad = int((((am_g != am_o) & live_c) & ((top - at) > 1e-4 * top.abs().clamp_min(1.0))).sum())
+    scores_ok = e_ner < 2e-5 and e_arc2 < 2e-3 and e_lab < 1e-3 and lab_flip_bad == 0
     arc_err = float((out["arc_logp"].cpu() - od["arc_logp"])[fin].abs().max())  # (padded dependents are not scored)
     flag = "" if dec_ok and scores_ok and not (d_heads or d_rels or d_ner or d_pos) else "  <-- look"
     bad += (not dec_ok) + (not scores_ok) + d_heads + d_rels + d_ner + d_pos
     print(f"case {case:3d} eng={engine} lin={int(lin)} dist={int(dist)} join={int(join)} E={E} TE={TE} H={H} U={U} O={Orel} T={T} B={B} L={L} ragged={int(ragged)}: decoder_exact={dec_ok} "
-          f"diff heads {d_heads} rels {d_rels} ner {d_ner} pos {d_pos}; max |arc_logp - oracle| {arc_err:.2e}; two-launch forms: ner {e_ner:.1e} arc {e_arc2:.1e}{flag}", flush=True)
+          f"diff heads {d_heads} rels {d_rels} ner {d_ner} pos {d_pos}; max |arc_logp - oracle| {arc_err:.2e}; two-launch forms: ner {e_ner:.1e} arc {e_arc2:.1e} dense labels {e_lab:.1e} (arg-max off a near-tie: {lab_flip_bad}){flag}", flush=True)
 print("total differing ids (and inexact decodes):", bad)
