@@ -19,9 +19,10 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 dev = torch.device("cuda:0")
 # FUZZ_MODE: letters l = every fourth case a long sentence batch (129..520 words), e = a random matrix engine per case,
-# f = random linearization / distance flags, s = every other case in the streaming form (join=False)
+# f = random linearization / distance flags, s = every other case in the streaming form (join=False), g = every third
+# case also captured as a HIP graph (TaskHeads.capture) and replayed on this and on a second batch: same ids as eager
 MODE = os.environ.get("FUZZ_MODE", "")
-LONG, ENGINES, FLAGS, STREAM = "l" in MODE, "e" in MODE, "f" in MODE, "s" in MODE
+LONG, ENGINES, FLAGS, STREAM, GRAPH = "l" in MODE, "e" in MODE, "f" in MODE, "s" in MODE, "g" in MODE
 bad = 0
 for case in range(n_cases):
     E = int(rng.choice([16, 24, 40, 64]))
@@ -48,6 +49,20 @@ for case in range(n_cases):
     out = heads.annotate_batch(enc_dep.to(dev), lens1 if case % 3 else torch.tensor(lens1, dtype=torch.int32, device=dev),
                                enc_tag.to(dev), lens if case % 3 else torch.tensor(lens, dtype=torch.int32, device=dev), join=join)
     torch.cuda.synchronize()
+    graph_ok = True
+    if GRAPH and case % 3 == 0:
+        cs = heads.capture(B, L, enc_dim=E)
+        enc2_dep, enc2_tag = S.make_encoder_outputs(B, L, E, seed=7000 + case)
+        for ed_, et_ in ((enc_dep, enc_tag), (enc2_dep, enc2_tag)):
+            cs.enc_dep.copy_(ed_); cs.enc_tag.copy_(et_)
+            cs.lens_dep.copy_(torch.tensor(lens1, dtype=torch.int32)); cs.lens_tag.copy_(torch.tensor(lens, dtype=torch.int32))
+            gout = {k_: v_.clone() for k_, v_ in cs.replay().items()}
+            torch.cuda.synchronize()
+            eo = heads.annotate_batch(ed_.to(dev), torch.tensor(lens1, dtype=torch.int32, device=dev), et_.to(dev),
+                                      torch.tensor(lens, dtype=torch.int32, device=dev))
+            torch.cuda.synchronize()
+            graph_ok = graph_ok and all(torch.equal(gout[k_], eo[k_]) for k_ in ("pos", "ner", "heads", "rels", "mst_status"))
+        del cs
     od = O.dep_heads(enc_dep, lens1, sd, linearization=lin, distance=dist)
     ot = O.tagger_heads(enc_tag, lens, sd)
     wh, ws = C.mst_batch(od["arc_logp"].numpy(), lens1)
@@ -92,8 +107,8 @@ for case in range(n_cases):
     lab_flip_bad = int((((am_g != am_o) & live_c) & ((top - at) > 1e-4 * top.abs().clamp_min(1.0))).sum())
     scores_ok = e_ner < 2e-5 and e_arc2 < 2e-3 and e_lab < 1e-3 and lab_flip_bad == 0
     arc_err = float((out["arc_logp"].cpu() - od["arc_logp"])[fin].abs().max())  # (padded dependents are not scored)
-    flag = "" if dec_ok and scores_ok and not (d_heads or d_rels or d_ner or d_pos) else "  <-- look"
-    bad += (not dec_ok) + (not scores_ok) + d_heads + d_rels + d_ner + d_pos
-    print(f"case {case:3d} eng={engine} lin={int(lin)} dist={int(dist)} join={int(join)} E={E} TE={TE} H={H} U={U} O={Orel} T={T} B={B} L={L} ragged={int(ragged)}: decoder_exact={dec_ok} "
+    flag = "" if dec_ok and scores_ok and graph_ok and not (d_heads or d_rels or d_ner or d_pos) else "  <-- look"
+    bad += (not dec_ok) + (not scores_ok) + (not graph_ok) + d_heads + d_rels + d_ner + d_pos
+    print(f"case {case:3d} eng={engine} lin={int(lin)} dist={int(dist)} join={int(join)} E={E} TE={TE} H={H} U={U} O={Orel} T={T} B={B} L={L} ragged={int(ragged)}: decoder_exact={dec_ok} graph_equals_eager={graph_ok} "
           f"diff heads {d_heads} rels {d_rels} ner {d_ner} pos {d_pos}; max |arc_logp - oracle| {arc_err:.2e}; two-launch forms: ner {e_ner:.1e} arc {e_arc2:.1e} dense labels {e_lab:.1e} (arg-max off a near-tie: {lab_flip_bad}){flag}", flush=True)
 print("total differing ids (and inexact decodes):", bad)
