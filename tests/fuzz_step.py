@@ -18,7 +18,7 @@ from phonlp_amd import synthetic as S  # noqa: E402
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 dev = torch.device("cuda:0")
-# FUZZ_MODE: letters l = every fourth case a long sentence batch (129..520 words), e = a random matrix engine per case,
+# FUZZ_MODE: letters r = the reference's head sizes (768 / 100 / 400 / 24 / 33 / 9), l = every fourth case a long sentence batch (129..520 words), e = a random matrix engine per case,
 # f = random linearization / distance flags, s = every other case in the streaming form (join=False), g = every third
 # case also captured as a HIP graph (TaskHeads.capture) and replayed on this and on a second batch: same ids as eager
 MODE = os.environ.get("FUZZ_MODE", "")
@@ -34,6 +34,9 @@ for case in range(n_cases):
     B = int(rng.integers(1, 41))
     L = int(rng.integers(2, 141))
     ragged = bool(rng.integers(0, 2))
+    if "r" in MODE:  # the reference's head sizes
+        E, TE, H, U, Orel, T = 768, 100, 400, 24, 33, 9
+        B, L = int(rng.integers(1, 25)), int(rng.integers(2, 101))
     if LONG and case % 4 == 0:  # long sentences: the arc kernel's LONG form, the round-based decode in global memory, unfused labels
         B, L = int(rng.integers(1, 7)), int(rng.integers(129, 521))
     engine = int(rng.integers(0, 3)) if ENGINES else 2
