@@ -413,18 +413,37 @@ __global__ __launch_bounds__(256) void mst_fast_kernel(MstArgs a, int pitch, int
                     bi = gt ? (j | (ca[q] << 8)) : bi;
                     bv = gt ? v : bv;
                 }
-                fast_argmax_step_d<DPP_XOR1>(bv, bi, dup, tau);
-                fast_argmax_step_d<DPP_XOR2>(bv, bi, dup, tau);
-                fast_argmax_step_d<DPP_HALF_MIRROR>(bv, bi, dup, tau);
-                fast_argmax_step_d<DPP_MIRROR>(bv, bi, dup, tau);
+                // The wave's arg-max with its margin flag WITHOUT moving (value, index, flag) triples through six exchange
+                // steps: the maximum alone is reduced (four DPP steps inside the 16-lane rows, the four rows' results read
+                // as scalars), the winner is the first lane that holds it, and "the runner-up is within tau" = the winner's
+                // own in-lane flag, or ANY other lane's best within tau of the maximum (a ballot).  The same predicate as the
+                // pairwise merges' (a merge keeps the winner's flag and ORs in the distance of the two maxima: along the
+                // winner's path that is every other lane's best against the maximum), a third of the cycles.
+                double m = bv;
+                m = fmax(m, fdpp_d<DPP_XOR1>(m));
+                m = fmax(m, fdpp_d<DPP_XOR2>(m));
+                m = fmax(m, fdpp_d<DPP_HALF_MIRROR>(m));
+                m = fmax(m, fdpp_d<DPP_MIRROR>(m));
+                {
+                    const long long mb = __double_as_longlong(m);
+                    const int lo = (int)(mb & 0xFFFFFFFFll), hi = (int)(mb >> 32);
+                    double r4[4];
 #pragma unroll
-                for (int o = 16; o <= 32; o <<= 1)
-                    fast_argmax_merge_d(bv, bi, dup, __shfl_xor(bv, o), __shfl_xor(bi, o), __shfl_xor(dup, o), tau);
+                    for (int w4 = 0; w4 < 4; ++w4) {
+                        const int l4 = __builtin_amdgcn_readlane(lo, 16 * w4), h4 = __builtin_amdgcn_readlane(hi, 16 * w4);
+                        r4[w4] = __longlong_as_double(((long long)h4 << 32) | (unsigned)l4);
+                    }
+                    m = fmax(fmax(r4[0], r4[1]), fmax(r4[2], r4[3]));
+                }
+                const unsigned long long wmask = __ballot(bv == m && bv > NEG_INF_D);
+                const int wl = wmask ? __builtin_ctzll(wmask) : 0;  // wave-uniform
+                const bool others_near = __ballot(lane != wl && (m - bv) <= tau) != 0ull;  // (-inf lanes: +inf or NaN, false)
+                const int wbi = __builtin_amdgcn_readlane(bi, wl), wdup = __builtin_amdgcn_readlane(dup, wl);
                 if (lane == 0) {
-                    selI[R] = (bi >> 8) & 0x7F;
-                    selJ[R] = bi & 0xFF;
-                    selV[R] = bv;
-                    if (dup || (bi & 0x8000) || !(bv > NEG_INF_D)) sc[FS_BAD2] = 1;
+                    selI[R] = (wbi >> 8) & 0x7F;
+                    selJ[R] = wbi & 0xFF;
+                    selV[R] = m;
+                    if (!wmask || wdup || others_near || (wbi & 0x8000)) sc[FS_BAD2] = 1;
                 }
             }
         };
