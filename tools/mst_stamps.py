@@ -39,6 +39,9 @@ if fast:  # round-based kernel: phase 1 = rows [0, B), phase 2 = rows [B, 5B) (o
             if k == 0 and L > 128:
                 print(f"  rows rescanned per round {x[:,9].sum()/max(x[:,8].sum(),1):.1f}")
             print(f"  {n:14s} share {100*x[:,k].sum()/tot.sum():5.1f}%   {per} {x[:,k].sum()/max(den,1):8.0f} cyc")
+        for k in (12, 13, 14, 15):  # extra stamps of a diagnostic build, if any (cycles per round; not part of `tot`)
+            if x[:, k].sum() > 0:
+                print(f"  extra stamp {k}: per round {x[:,k].sum()/max(x[:,8].sum(),1):8.0f} cyc")
     sys.exit(0)
 names = ["init", "argmax", "cycles", "lists", "edge+sum", "enter/leave+rec", "contract", "expand", "oneroot", "-", "-", "-", "rescan"]
 tot = d[:, :9].sum(1) + d[:, 12]
